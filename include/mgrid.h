@@ -1,0 +1,188 @@
+/*
+ * mgrid.h — C ABI of the MI355X-native batched MultiGrid step path.
+ *
+ * The reference (cxh42/multigrid) is pure Python and has no FFI: its boundary is the
+ * duck-typed gym-0.23 env object (`reset()` / `step(actions)`), see
+ *   envs/gym_multigrid/multigrid.py:466-501  (MultiGridEnv.reset)
+ *   envs/gym_multigrid/multigrid.py:963-995  (MultiGridEnv.step)
+ *   envs/gym_multigrid/multigrid.py:1037-1083 (gen_obs / gen_agent_obs)
+ *   v8_robust_ppo.py:171-220                 (v8 reward shaping, fused into step here)
+ * Every entry point below names the reference call it replaces.  The library keeps N
+ * independent envs resident in HBM as struct-of-arrays and advances all of them with one
+ * kernel launch per call.
+ *
+ * Conventions
+ *  - every function returns MG_OK (0) or a negative MG_E* code; never throws, never aborts.
+ *    mg_last_error() returns the thread-local text of the last failure.
+ *  - a handle is bound to one HIP device and one stream.  Calls on one handle are not
+ *    re-entrant; different handles may be driven from different host threads.
+ *  - reset/step calls are asynchronous on the handle's stream; mg_sync() blocks.
+ *  - all per-env arrays are AGENT-MAJOR: element (agent a, env n) lives at a*env_stride + n,
+ *    where env_stride = mg_buffers.env_stride (n_envs rounded up to a multiple of 64).
+ *    This mirrors the reference's obs dict, whose 'image'/'direction' entries are lists
+ *    indexed by agent first (multigrid.py:1060-1063).
+ *  - the library owns all device buffers; mg_get_buffers() hands out borrowed device
+ *    pointers that stay valid until mg_destroy().
+ */
+#ifndef MGRID_H
+#define MGRID_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_OK            0
+#define MG_EINVAL       -1  /* bad argument / config */
+#define MG_EHIP         -2  /* HIP runtime error (text in mg_last_error) */
+#define MG_ENOMEM       -3
+#define MG_EUNSUPPORTED -4  /* config outside what the kernels were instantiated for */
+#define MG_ESTATE       -5  /* call order (e.g. step before map/reset) */
+
+/* shaping_kind */
+#define MG_SHAPING_NONE 0   /* reward = env reward (multigrid.py:881-883) */
+#define MG_SHAPING_V8   1   /* reward = v8_robust_ppo.py:171-220 shaped reward */
+
+/* action_dtype */
+#define MG_ACT_U8  1
+#define MG_ACT_I32 4
+#define MG_ACT_I64 8
+
+/* cell encoding = gym-minigrid OBJECT_TO_IDX / COLOR_TO_IDX / door state */
+#define MG_T_UNSEEN 0
+#define MG_T_EMPTY  1
+#define MG_T_WALL   2
+#define MG_T_FLOOR  3
+#define MG_T_DOOR   4
+#define MG_T_KEY    5
+#define MG_T_BALL   6
+#define MG_T_BOX    7
+#define MG_T_GOAL   8
+#define MG_T_LAVA   9
+#define MG_T_AGENT 10
+
+/* bits of the device error word (mg_check_errors) */
+#define MG_ERR_BAD_ACTION   1u  /* action outside [0,6]   (multigrid.py:902 assert) */
+#define MG_ERR_BAD_RESPAWN  2u  /* injected respawn/spawn cell occupied or out of range */
+#define MG_ERR_BAD_ORDER    4u  /* injected order is not a permutation */
+#define MG_ERR_MISSING_DRAW 8u  /* replay step needed a respawn/spawn that was not injected */
+
+/* Mirrors the ctor kwargs of MultiGridEnv (multigrid.py:325-339) + ClutteredMultiGrid
+ * (cluttered.py:16-23), plus batching/sharding fields that have no reference counterpart. */
+typedef struct mg_config {
+  int32_t width;             /* grid width  W (multigrid.py:446) */
+  int32_t height;            /* grid height H */
+  int32_t n_agents;          /* A (multigrid.py:375) */
+  int32_t view_size;         /* agent_view_size V, odd (multigrid.py:387) */
+  int32_t max_steps;         /* multigrid.py:448 */
+  int32_t see_through_walls; /* multigrid.py:449, 1020-1024 */
+  int32_t competitive;       /* multigrid.py:378-381 (forced on when n_agents == 1) */
+  int32_t shaping_kind;      /* MG_SHAPING_* */
+  int32_t auto_reset;        /* 1: an env whose step returns done is reset inside the same
+                                kernel and the obs written is the post-reset obs (gym vector
+                                autoreset; v7_stable_goal_focused_ppo.py:334-340 is the only
+                                reference precedent).  0: reference behaviour, caller resets. */
+  int32_t action_dtype;      /* MG_ACT_* : element type of the actions array */
+  int32_t emit_env_reward;   /* 1: also write the unshaped env reward (mg_buffers.env_reward) */
+  int32_t reserved0;
+  int64_t n_envs;            /* envs held by THIS handle (this GPU's shard) */
+  int64_t env_id_base;       /* global id of local env 0; Philox streams are keyed by the
+                                global id so results do not depend on the sharding */
+  uint64_t seed;             /* Philox key for free-running mode */
+} mg_config;
+
+typedef struct mg_buffers {
+  int64_t  n_envs;
+  int64_t  env_stride;   /* elements between consecutive agents' rows (multiple of 64) */
+  int32_t  n_agents;
+  int32_t  obs_cell_bytes; /* V*V*3 : bytes of one agent's image, [vx][vy][(type,color,state)]
+                              exactly as Grid.encode lays it out */
+  uint8_t* obs_image;    /* [A][env_stride][V*V*3]  — obs['image'][a]   */
+  uint8_t* obs_dir;      /* [A][env_stride]         — obs['direction'][a] */
+  double*  reward;       /* [A][env_stride]  rewards[a] (shaped when shaping_kind != NONE) */
+  double*  env_reward;   /* [A][env_stride]  unshaped env reward, NULL unless emit_env_reward */
+  uint8_t* done;         /* [env_stride]     collective done of the step just taken */
+  uint32_t* agent_state; /* [A][env_stride]  x | y<<8 | dir<<16 | carrying<<24 (post-step,
+                              post-respawn: what v8 reads as env.agent_pos[a], v8:242) */
+  uint32_t* shaper_state;/* [A][env_stride]  prev_x | prev_y<<8 | valid<<16 | stationary<<17 */
+  uint32_t* step_state;  /* [env_stride]     step_count | agent done bits << 16 */
+} mg_buffers;
+
+typedef struct mg_handle mg_handle;
+
+/* gym.make(env_id) + ctor (v8_robust_ppo.py:124; multigrid.py:325-464).  Allocates all
+ * device state for cfg->n_envs envs on `device`.  No map yet: call mg_set_static_map. */
+int mg_create(const mg_config* cfg, int device, mg_handle** out);
+
+/* env.close() (v8_robust_ppo.py:383). */
+int mg_destroy(mg_handle* h);
+
+/* Result of _gen_grid's static part (cluttered.py:25-36): one layout shared by every env.
+ * cells = host pointer, uint8[W*H*3] indexed [(y*W+x)*3 + c] = (type,color,state).
+ * Only empty/wall/goal/lava cells are accepted (MG_EUNSUPPORTED otherwise): the shared map
+ * is immutable, which holds for exactly these object kinds (nothing pickable, nothing
+ * toggleable, nothing an agent can walk onto and destroy — multigrid.py:842-845,926-961). */
+int mg_set_static_map(mg_handle* h, const uint8_t* cells);
+
+/* env.reset() (multigrid.py:466-501) for every env whose mask byte is non-zero (mask = device
+ * pointer uint8[n_envs], or NULL for all).  Spawns are drawn on device (Philox) with the
+ * reference's distribution: uniform rejection sampling over the grid for an empty cell not
+ * holding an agent, then uniform direction (multigrid.py:598-619, 665-666).  Writes obs. */
+int mg_reset(mg_handle* h, const uint8_t* env_mask);
+
+/* Same, with the spawn the reference's time-seeded RNG would have produced injected:
+ * spawn = device pointer int8[A][env_stride][4] = (x, y, dir, 0) (cluttered.py:55-63). */
+int mg_reset_inject(mg_handle* h, const uint8_t* env_mask, const int8_t* spawn);
+
+/* env.step(actions) (multigrid.py:963-995) for all envs, free-running: the agent order
+ * (multigrid.py:973-974) and respawns (multigrid.py:815-832) are drawn on device (Philox).
+ * actions = device pointer [A][env_stride] of cfg.action_dtype. */
+int mg_step(mg_handle* h, const void* actions);
+
+/* env.step(actions) with the reference's two RNG streams injected (bit-exact replay):
+ *   order   = device uint8[A][env_stride]: order[k][n] = agent acting k-th (the shuffled
+ *             np.arange of multigrid.py:973-974)
+ *   respawn = device int8[A][env_stride][4] = (x,y,dir,0) accepted by place_one_agent for
+ *             agent a if it finishes this step (multigrid.py:832), x = -1 if none recorded
+ *   reset_spawn = same layout, used when auto_reset fires; may be NULL when auto_reset == 0 */
+int mg_step_replay(mg_handle* h, const void* actions, const uint8_t* order,
+                   const int8_t* respawn, const int8_t* reset_spawn);
+
+/* Synthetic-rollout step: like mg_step but the actions are drawn on device too
+ * (uniform in [0,6], the "random actions" of BASELINE.json configs) and also stored to
+ * `actions_out` (device [A][env_stride] uint8, may be NULL). */
+int mg_step_random(mg_handle* h, uint8_t* actions_out);
+
+int mg_get_buffers(mg_handle* h, mg_buffers* out);
+
+/* Stream control: by default the handle owns a stream; mg_set_stream adopts the caller's
+ * (e.g. torch's current stream) — pass a hipStream_t cast to void*. */
+int mg_set_stream(mg_handle* h, void* hip_stream);
+int mg_get_stream(mg_handle* h, void** hip_stream);
+int mg_sync(mg_handle* h);
+
+/* Number of steps taken so far (the Philox step index of the next step). */
+int mg_get_step_index(mg_handle* h, uint64_t* out);
+int mg_set_step_index(mg_handle* h, uint64_t t);
+
+/* Synchronises, returns and clears the device error word (MG_ERR_* bits). */
+int mg_check_errors(mg_handle* h, uint32_t* out);
+
+/* Goal cell the v8 shaper measures distance to (v8_robust_ppo.py:159-169: first 'goal' cell
+ * scanning x-major, (13,13) if none). */
+int mg_get_goal(mg_handle* h, int32_t* gx, int32_t* gy);
+
+/* Test hook, host only (no GPU call, no reference counterpart): evaluates the kernels' bitmask
+ * form of Grid.process_vis on n opacity patterns so that it can be compared
+ * exhaustively with the oracle's literal loops.  V in {3,5,7}; bit (i*V+j) of a pattern = view
+ * cell (vx=i, vy=j) is opaque; `out` uses the same bit layout for "visible". */
+int mg_debug_vis_masks(int V, const uint64_t* patterns, int64_t n, uint64_t* out);
+
+const char* mg_last_error(void);
+const char* mg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGRID_H */

@@ -1,0 +1,193 @@
+"""BatchedMultiGrid — N device-resident MultiGrid envs behind the C ABI (include/mgrid.h).
+
+Host-side mirror of the reference env object (envs/gym_multigrid/multigrid.py:322-1083) for the
+batched case: `reset()` / `step(actions)` keep the reference's meaning, but every quantity is a
+torch tensor aliasing the library's device buffers (zero copy), agent-major like the reference's
+obs dict (`obs['image'][a]`, multigrid.py:1060-1063).  PyTorch is plumbing only (device
+memory views, streams); all compute is in libmgrid.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+
+class _DevArray:
+  """Minimal __cuda_array_interface__ holder so torch can alias a raw device pointer."""
+
+  def __init__(self, ptr, shape, typestr):
+    self.__cuda_array_interface__ = {
+        'shape': tuple(int(s) for s in shape), 'typestr': typestr, 'data': (int(ptr), False),
+        'version': 2, 'strides': None}
+
+
+def _alias(ptr, shape, typestr, device):
+  return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device)
+
+
+_ACT = {'u8': (_lib.ACT_U8, torch.uint8), 'i32': (_lib.ACT_I32, torch.int32), 'i64': (_lib.ACT_I64, torch.int64)}
+
+
+class BatchedMultiGrid:
+  def __init__(self, cells, n_envs, n_agents=3, view_size=5, max_steps=100, see_through_walls=False,
+               competitive=False, shaping='v8', auto_reset=True, action_dtype='u8', device=0, seed=0,
+               env_id_base=0, emit_env_reward=False, use_torch_stream=True):
+    self.L = _lib.load()
+    cells = np.ascontiguousarray(cells, dtype=np.uint8)
+    assert cells.ndim == 3 and cells.shape[2] == 3, 'cells must be uint8[H, W, 3]'
+    self.height, self.width = int(cells.shape[0]), int(cells.shape[1])
+    self.n_envs, self.n_agents, self.view_size, self.max_steps = int(n_envs), int(n_agents), int(view_size), int(max_steps)
+    self.device_index = int(device)
+    self.device = torch.device('cuda', self.device_index)
+    self.act_code, self.act_torch = _ACT[action_dtype]
+    cfg = _lib.MgConfig(
+        width=self.width, height=self.height, n_agents=n_agents, view_size=view_size, max_steps=max_steps,
+        see_through_walls=int(see_through_walls), competitive=int(competitive),
+        shaping_kind={None: 0, 'none': 0, 'v8': 1}[shaping], auto_reset=int(auto_reset),
+        action_dtype=self.act_code, emit_env_reward=int(emit_env_reward), reserved0=0,
+        n_envs=n_envs, env_id_base=env_id_base, seed=seed)
+    self.h = C.c_void_p()
+    _lib.check(self.L.mg_create(C.byref(cfg), self.device_index, C.byref(self.h)))
+    self.cfg = cfg
+    self.cells = cells
+    _lib.check(self.L.mg_set_static_map(self.h, cells.ctypes.data_as(C.c_void_p)))
+    if use_torch_stream:
+      s = torch.cuda.current_stream(self.device)
+      _lib.check(self.L.mg_set_stream(self.h, C.c_void_p(s.cuda_stream)))
+    b = _lib.MgBuffers()
+    _lib.check(self.L.mg_get_buffers(self.h, C.byref(b)))
+    self.stride = S = int(b.env_stride)
+    A, V, n, dev = self.n_agents, self.view_size, self.n_envs, self.device
+    # full-stride tensors (what the kernels address) ...
+    self._obs_image = _alias(b.obs_image, (A, S, V, V, 3), '|u1', dev)
+    self._obs_dir = _alias(b.obs_dir, (A, S), '|u1', dev)
+    self._reward = _alias(b.reward, (A, S), '<f8', dev)
+    self._env_reward = _alias(b.env_reward, (A, S), '<f8', dev) if b.env_reward else None
+    self._done = _alias(b.done, (S,), '|u1', dev)
+    self._agent_state = _alias(b.agent_state, (A, S), '<i4', dev)
+    self._shaper_state = _alias(b.shaper_state, (A, S), '<i4', dev)
+    self._step_state = _alias(b.step_state, (S,), '<i4', dev)
+    # ... and the [:, :n_envs] views callers use
+    self.obs_image = self._obs_image[:, :n]      # obs['image'][a]     uint8[A, N, V, V, 3]
+    self.obs_dir = self._obs_dir[:, :n]          # obs['direction'][a] uint8[A, N]
+    self.reward = self._reward[:, :n]            # rewards[a]          float64[A, N]
+    self.env_reward = None if self._env_reward is None else self._env_reward[:, :n]
+    self.done = self._done[:n]                   # collective done     uint8[N]
+    self.agent_state = self._agent_state[:, :n]
+    self.shaper_state = self._shaper_state[:, :n]
+    self.step_state = self._step_state[:n]
+    # action staging buffer in the layout the kernel reads
+    self.actions = torch.zeros((A, S), dtype=self.act_torch, device=dev)
+    gx, gy = C.c_int32(), C.c_int32()
+    _lib.check(self.L.mg_get_goal(self.h, C.byref(gx), C.byref(gy)))
+    self.goal_pos = (gx.value, gy.value)
+
+  # ---- lifetime -----------------------------------------------------------------------------
+  def close(self):
+    if getattr(self, 'h', None) is not None and self.h:
+      self.L.mg_destroy(self.h)
+      self.h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  # ---- helpers ------------------------------------------------------------------------------
+  def _dev_ptr(self, t, dtype, shape_tail=()):
+    """Device pointer of `t` laid out [A, stride, *tail]; copies into a padded buffer if needed."""
+    if t is None:
+      return None, None
+    t = torch.as_tensor(t, device=self.device)
+    if t.dtype != dtype:
+      t = t.to(dtype)
+    full = (self.n_agents, self.stride) + tuple(shape_tail)
+    if tuple(t.shape) != full:
+      assert tuple(t.shape) == (self.n_agents, self.n_envs) + tuple(shape_tail), (tuple(t.shape), full)
+      buf = torch.zeros(full, dtype=dtype, device=self.device)
+      buf[:, :self.n_envs] = t
+      t = buf
+    t = t.contiguous()
+    return C.c_void_p(t.data_ptr()), t
+
+  def _mask_ptr(self, mask):
+    if mask is None:
+      return None, None
+    m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+    assert m.numel() >= self.n_envs
+    return C.c_void_p(m.data_ptr()), m
+
+  def obs(self):
+    return {'image': self.obs_image, 'direction': self.obs_dir}
+
+  @property
+  def agent_pos(self):
+    """int32[A, N, 2] (x, y) — env.agent_pos[a] (v8_robust_ppo.py:242)."""
+    s = self.agent_state
+    return torch.stack((s & 255, (s >> 8) & 255), dim=-1)
+
+  @property
+  def agent_dir(self):
+    return (self.agent_state >> 16) & 3
+
+  @property
+  def step_count(self):
+    return self.step_state & 0xFFFF
+
+  # ---- reference contract -------------------------------------------------------------------
+  def reset(self, mask=None, spawn=None):
+    """env.reset() for all envs (or those in `mask`).  spawn: int8[A, N, 4] (x,y,dir,0) to inject."""
+    mp, _m = self._mask_ptr(mask)
+    if spawn is None:
+      _lib.check(self.L.mg_reset(self.h, mp))
+    else:
+      sp, _s = self._dev_ptr(spawn, torch.int8, (4,))
+      _lib.check(self.L.mg_reset_inject(self.h, mp, sp))
+    return self.obs()
+
+  def step(self, actions=None):
+    """env.step(actions): actions [A, N] (or the preloaded self.actions when None)."""
+    if actions is None:
+      ap, _a = C.c_void_p(self.actions.data_ptr()), self.actions
+    else:
+      ap, _a = self._dev_ptr(actions, self.act_torch)
+    _lib.check(self.L.mg_step(self.h, ap))
+    return self.obs(), self.reward, self.done, {}
+
+  def step_replay(self, actions, order, respawn, reset_spawn=None):
+    ap, _a = self._dev_ptr(actions, self.act_torch)
+    op, _o = self._dev_ptr(order, torch.uint8)
+    rp, _r = self._dev_ptr(respawn, torch.int8, (4,))
+    sp, _s = self._dev_ptr(reset_spawn, torch.int8, (4,))
+    _lib.check(self.L.mg_step_replay(self.h, ap, op, rp, sp))
+    return self.obs(), self.reward, self.done, {}
+
+  def step_random(self, actions_out=None):
+    """One step with on-device uniform random actions (synthetic rollouts)."""
+    ptr = None
+    if actions_out is not None:
+      assert actions_out.dtype == torch.uint8 and tuple(actions_out.shape) == (self.n_agents, self.stride)
+      ptr = C.c_void_p(actions_out.data_ptr())
+    _lib.check(self.L.mg_step_random(self.h, ptr))
+    return self.obs(), self.reward, self.done, {}
+
+  def sync(self):
+    _lib.check(self.L.mg_sync(self.h))
+
+  def check_errors(self):
+    e = C.c_uint32()
+    _lib.check(self.L.mg_check_errors(self.h, C.byref(e)))
+    return e.value
+
+  @property
+  def step_index(self):
+    t = C.c_uint64()
+    _lib.check(self.L.mg_get_step_index(self.h, C.byref(t)))
+    return t.value
+
+  @step_index.setter
+  def step_index(self, t):
+    _lib.check(self.L.mg_set_step_index(self.h, int(t)))

@@ -1,0 +1,80 @@
+"""ctypes binding of include/mgrid.h.  Fails loudly when libmgrid.so is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmgrid.so')
+
+MG_OK = 0
+SHAPING_NONE, SHAPING_V8 = 0, 1
+ACT_U8, ACT_I32, ACT_I64 = 1, 4, 8
+ERR_BAD_ACTION, ERR_BAD_RESPAWN, ERR_BAD_ORDER, ERR_MISSING_DRAW = 1, 2, 4, 8
+
+
+class MgConfig(C.Structure):
+  _fields_ = [
+      ('width', C.c_int32), ('height', C.c_int32), ('n_agents', C.c_int32), ('view_size', C.c_int32),
+      ('max_steps', C.c_int32), ('see_through_walls', C.c_int32), ('competitive', C.c_int32),
+      ('shaping_kind', C.c_int32), ('auto_reset', C.c_int32), ('action_dtype', C.c_int32),
+      ('emit_env_reward', C.c_int32), ('reserved0', C.c_int32),
+      ('n_envs', C.c_int64), ('env_id_base', C.c_int64), ('seed', C.c_uint64),
+  ]
+
+
+class MgBuffers(C.Structure):
+  _fields_ = [
+      ('n_envs', C.c_int64), ('env_stride', C.c_int64), ('n_agents', C.c_int32), ('obs_cell_bytes', C.c_int32),
+      ('obs_image', C.c_void_p), ('obs_dir', C.c_void_p), ('reward', C.c_void_p), ('env_reward', C.c_void_p),
+      ('done', C.c_void_p), ('agent_state', C.c_void_p), ('shaper_state', C.c_void_p), ('step_state', C.c_void_p),
+  ]
+
+
+# name -> (restype, argtypes): every symbol include/mgrid.h declares
+SYMBOLS = {
+    'mg_create': (C.c_int, [C.POINTER(MgConfig), C.c_int, C.POINTER(C.c_void_p)]),
+    'mg_destroy': (C.c_int, [C.c_void_p]),
+    'mg_set_static_map': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mg_reset': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mg_reset_inject': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mg_step': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mg_step_replay': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mg_step_random': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mg_get_buffers': (C.c_int, [C.c_void_p, C.POINTER(MgBuffers)]),
+    'mg_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mg_get_stream': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    'mg_sync': (C.c_int, [C.c_void_p]),
+    'mg_get_step_index': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    'mg_set_step_index': (C.c_int, [C.c_void_p, C.c_uint64]),
+    'mg_check_errors': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    'mg_get_goal': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'mg_debug_vis_masks': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    'mg_last_error': (C.c_char_p, []),
+    'mg_version': (C.c_char_p, []),
+}
+
+_LIB = None
+
+
+class MgError(RuntimeError):
+  pass
+
+
+def load():
+  global _LIB
+  if _LIB is None:
+    if not os.path.exists(LIB_PATH):
+      raise ImportError(
+          'multigrid_amd: %s is missing. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+          '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+      fn = getattr(lib, name)   # AttributeError if the library does not export it
+      fn.restype = res
+      fn.argtypes = args
+    _LIB = lib
+  return _LIB
+
+
+def check(rc):
+  if rc != MG_OK:
+    raise MgError('mgrid error %d: %s' % (rc, load().mg_last_error().decode()))

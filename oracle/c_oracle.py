@@ -1,0 +1,268 @@
+"""ctypes front-end of oracle/mg_oracle.c (TEST INFRASTRUCTURE — see oracle/__init__.py).
+
+`OracleBatch` keeps n independent oracle envs and exposes reset/step over numpy arrays laid out
+exactly like the product's device buffers (agent-major, env_stride), so a parity test is a
+plain `np.array_equal` per buffer.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+u8p = C.POINTER(C.c_uint8)
+i8p = C.POINTER(C.c_int8)
+f64p = C.POINTER(C.c_double)
+i32p = C.POINTER(C.c_int)
+
+
+def build(force=False):
+  so = os.path.join(_HERE, 'libmgoracle.so')
+  src = os.path.join(_HERE, 'mg_oracle.c')
+  if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    subprocess.check_call(['make', '-s', '-C', _HERE, 'libmgoracle.so'])
+  return so
+
+
+def lib():
+  global _LIB
+  if _LIB is None:
+    so = os.path.join(_HERE, 'libmgoracle.so')
+    if not os.path.exists(so):
+      build()
+    L = C.CDLL(so)
+    L.mgo_create.restype = C.c_void_p
+    L.mgo_create.argtypes = [C.c_int] * 9 + [C.c_uint64, C.c_uint64]
+    L.mgo_destroy.argtypes = [C.c_void_p]
+    L.mgo_set_map.argtypes = [C.c_void_p, u8p]
+    L.mgo_reset.argtypes = [C.c_void_p, i8p, C.c_uint64]
+    L.mgo_get_obs.argtypes = [C.c_void_p, u8p, u8p]
+    L.mgo_step.argtypes = [C.c_void_p, i32p, u8p, i8p, i8p, C.c_uint64, u8p, u8p, f64p, f64p, u8p]
+    L.mgo_random_actions.argtypes = [C.c_void_p, C.c_uint64, i32p]
+    L.mgo_agent_state.restype = C.c_uint32
+    L.mgo_agent_state.argtypes = [C.c_void_p, C.c_int]
+    L.mgo_shaper_state.restype = C.c_uint32
+    L.mgo_shaper_state.argtypes = [C.c_void_p, C.c_int]
+    L.mgo_step_state.restype = C.c_uint32
+    L.mgo_step_state.argtypes = [C.c_void_p]
+    L.mgo_last_draws.argtypes = [C.c_void_p, u8p, i8p, i8p]
+    L.mgo_errors.restype = C.c_uint32
+    L.mgo_errors.argtypes = [C.c_void_p]
+    L.mgo_get_grid.argtypes = [C.c_void_p, u8p]
+    L.mgo_put_obj.argtypes = [C.c_void_p] + [C.c_int] * 5
+    L.mgo_set_step_count.argtypes = [C.c_void_p, C.c_int]
+    L.mgo_goal.argtypes = [C.c_void_p, i32p, i32p]
+    L.mgo_reward_value.restype = C.c_double
+    L.mgo_reward_value.argtypes = [C.c_int, C.c_int]
+    L.mgo_process_vis.argtypes = [C.c_int, u8p, u8p]
+    L.mgo_philox.argtypes = [C.POINTER(C.c_uint32)] * 3
+    L.mgo_batch_reset.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, i8p, C.c_uint64, u8p, u8p]
+    L.mgo_batch_step.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, u8p, i8p, i8p,
+                                 C.c_uint64, u8p, u8p, f64p, f64p, u8p, u8p]
+    _LIB = L
+  return _LIB
+
+
+def _p(arr, typ):
+  return None if arr is None else arr.ctypes.data_as(typ)
+
+
+def philox(ctr, key):
+  c = (C.c_uint32 * 4)(*ctr)
+  k = (C.c_uint32 * 2)(*key)
+  o = (C.c_uint32 * 4)()
+  lib().mgo_philox(c, k, o)
+  return list(o)
+
+
+def process_vis(V, opaque):
+  """Literal minigrid process_vis on a VxV opacity pattern; opaque[i,j] (i = view x)."""
+  op = np.ascontiguousarray(opaque, dtype=np.uint8).reshape(V * V)
+  m = np.zeros(V * V, np.uint8)
+  lib().mgo_process_vis(V, _p(op, u8p), _p(m, u8p))
+  return m.reshape(V, V).astype(bool)
+
+
+def reward_value(step_count, max_steps):
+  return lib().mgo_reward_value(step_count, max_steps)
+
+
+class OracleEnv:
+  """One oracle env with the reference's (obs, rewards, done, info) call shape."""
+
+  def __init__(self, cells, W=15, H=15, A=3, V=5, max_steps=100, see_through=0, competitive=0,
+               shaping=0, auto_reset=0, seed=0, gid=0):
+    self.L = lib()
+    self.W, self.H, self.A, self.V = W, H, A, V
+    self.h = self.L.mgo_create(W, H, A, V, max_steps, see_through, competitive, shaping, auto_reset, seed, gid)
+    if not self.h:
+      raise ValueError('bad oracle config')
+    cells = np.ascontiguousarray(cells, dtype=np.uint8).reshape(W * H * 3)
+    self.L.mgo_set_map(self.h, _p(cells, u8p))
+    self.t = 0
+
+  def __del__(self):
+    if getattr(self, 'h', None):
+      self.L.mgo_destroy(self.h)
+      self.h = None
+
+  def _obs(self):
+    img = np.zeros((self.A, self.V, self.V, 3), np.uint8)
+    d = np.zeros(self.A, np.uint8)
+    self.L.mgo_get_obs(self.h, _p(img, u8p), _p(d, u8p))
+    return {'image': [img[a] for a in range(self.A)], 'direction': [int(x) for x in d]}
+
+  def reset(self, spawn=None):
+    sp = None
+    if spawn is not None:
+      sp = np.zeros((self.A, 4), np.int8)
+      sp[:, :3] = np.asarray(spawn, np.int8)
+    self.L.mgo_reset(self.h, _p(sp, i8p), self.t)
+    return self._obs()
+
+  def step(self, actions, order=None, respawn=None, reset_spawn=None):
+    act = np.asarray(actions, np.int32)
+    od = None if order is None else np.asarray(order, np.uint8)
+    rs = sp = None
+    if respawn is not None:
+      rs = np.zeros((self.A, 4), np.int8)
+      rs[:, :3] = np.asarray(respawn, np.int8)
+    if reset_spawn is not None:
+      sp = np.zeros((self.A, 4), np.int8)
+      sp[:, :3] = np.asarray(reset_spawn, np.int8)
+    img = np.zeros((self.A, self.V, self.V, 3), np.uint8)
+    d = np.zeros(self.A, np.uint8)
+    rw = np.zeros(self.A, np.float64)
+    er = np.zeros(self.A, np.float64)
+    dn = np.zeros(1, np.uint8)
+    self.L.mgo_step(self.h, _p(act, i32p), _p(od, u8p), _p(rs, i8p), _p(sp, i8p), self.t,
+                    _p(img, u8p), _p(d, u8p), _p(rw, f64p), _p(er, f64p), _p(dn, u8p))
+    self.t += 1
+    self.env_rewards = er
+    obs = {'image': [img[a] for a in range(self.A)], 'direction': [int(x) for x in d]}
+    return obs, list(rw), bool(dn[0]), {}
+
+  @property
+  def agent_pos(self):
+    return [np.array([s & 255, (s >> 8) & 255]) for s in self.agent_states()]
+
+  @property
+  def agent_dir(self):
+    return [(s >> 16) & 3 for s in self.agent_states()]
+
+  def agent_states(self):
+    return [self.L.mgo_agent_state(self.h, a) for a in range(self.A)]
+
+  def shaper_states(self):
+    return [self.L.mgo_shaper_state(self.h, a) for a in range(self.A)]
+
+  def step_state(self):
+    return self.L.mgo_step_state(self.h)
+
+  def errors(self):
+    return self.L.mgo_errors(self.h)
+
+  def grid(self):
+    g = np.zeros((self.H, self.W, 3), np.uint8)
+    self.L.mgo_get_grid(self.h, _p(g, u8p))
+    return g
+
+  def put_obj(self, x, y, type_, color=0, state=0):
+    self.L.mgo_put_obj(self.h, x, y, type_, color, state)
+
+  def set_step_count(self, s):
+    self.L.mgo_set_step_count(self.h, s)
+
+
+class OracleBatch:
+  """n oracle envs over the product's buffer layouts."""
+
+  def __init__(self, cells, n, W=15, H=15, A=3, V=5, max_steps=100, see_through=0, competitive=0,
+               shaping=0, auto_reset=0, seed=0, gid_base=0):
+    self.L = lib()
+    self.n, self.A, self.V, self.W, self.H = n, A, V, W, H
+    self.stride = (n + 63) // 64 * 64
+    cells = np.ascontiguousarray(cells, dtype=np.uint8).reshape(W * H * 3)
+    self.envs = (C.c_void_p * n)()
+    for i in range(n):
+      h = self.L.mgo_create(W, H, A, V, max_steps, see_through, competitive, shaping, auto_reset, seed, gid_base + i)
+      if not h:
+        raise ValueError('bad oracle config')
+      self.L.mgo_set_map(h, _p(cells, u8p))
+      self.envs[i] = h
+    cb = V * V * 3
+    s = self.stride
+    self.obs_image = np.zeros((A, s, cb), np.uint8)
+    self.obs_dir = np.zeros((A, s), np.uint8)
+    self.reward = np.zeros((A, s), np.float64)
+    self.env_reward = np.zeros((A, s), np.float64)
+    self.done = np.zeros(s, np.uint8)
+    self.t = 0
+
+  def __del__(self):
+    for i in range(getattr(self, 'n', 0)):
+      if self.envs[i]:
+        self.L.mgo_destroy(self.envs[i])
+        self.envs[i] = None
+
+  def reset(self, mask=None, spawn=None):
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    sp = None if spawn is None else np.ascontiguousarray(spawn, np.int8)
+    self.L.mgo_batch_reset(self.envs, self.n, self.stride, _p(m, u8p), _p(sp, i8p), self.t,
+                           _p(self.obs_image, u8p), _p(self.obs_dir, u8p))
+
+  def step(self, actions=None, order=None, respawn=None, reset_spawn=None, actions_out=None):
+    a = None if actions is None else np.ascontiguousarray(actions, np.uint8)
+    o = None if order is None else np.ascontiguousarray(order, np.uint8)
+    r = None if respawn is None else np.ascontiguousarray(respawn, np.int8)
+    s = None if reset_spawn is None else np.ascontiguousarray(reset_spawn, np.int8)
+    self.L.mgo_batch_step(self.envs, self.n, self.stride, _p(a, u8p), _p(o, u8p), _p(r, i8p), _p(s, i8p),
+                          self.t, _p(self.obs_image, u8p), _p(self.obs_dir, u8p), _p(self.reward, f64p),
+                          _p(self.env_reward, f64p), _p(self.done, u8p), _p(actions_out, u8p))
+    self.t += 1
+
+  def agent_state(self):
+    out = np.zeros((self.A, self.stride), np.uint32)
+    for i in range(self.n):
+      for a in range(self.A):
+        out[a, i] = self.L.mgo_agent_state(self.envs[i], a)
+    return out
+
+  def shaper_state(self):
+    out = np.zeros((self.A, self.stride), np.uint32)
+    for i in range(self.n):
+      for a in range(self.A):
+        out[a, i] = self.L.mgo_shaper_state(self.envs[i], a)
+    return out
+
+  def step_state(self):
+    out = np.zeros(self.stride, np.uint32)
+    for i in range(self.n):
+      out[i] = self.L.mgo_step_state(self.envs[i])
+    return out
+
+  def last_draws(self):
+    """(order uint8[A,stride], respawn int8[A,stride,4], spawn int8[A,stride,4]) of the last call."""
+    A, S = self.A, self.stride
+    order = np.zeros((A, S), np.uint8)
+    respawn = np.full((A, S, 4), -1, np.int8)
+    respawn[:, :, 2:] = 0
+    spawn = np.zeros((A, S, 4), np.int8)
+    o = np.zeros(A, np.uint8)
+    r = np.zeros((A, 4), np.int8)
+    s = np.zeros((A, 4), np.int8)
+    for i in range(self.n):
+      self.L.mgo_last_draws(self.envs[i], _p(o, u8p), _p(r, i8p), _p(s, i8p))
+      order[:, i] = o
+      respawn[:, i] = r
+      spawn[:, i] = s
+    return order, respawn, spawn
+
+  def errors(self):
+    e = 0
+    for i in range(self.n):
+      e |= self.L.mgo_errors(self.envs[i])
+    return e

@@ -1,0 +1,625 @@
+/*
+ * mg_oracle.c — CPU restatement of the reference's MultiGrid step path.  TEST INFRASTRUCTURE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * library; the product (multigrid_amd/) never does.
+ *
+ * PARITY STATUS: "parity unpinned" for everything except MiniGridEnv._reward.
+ *   The reference (cxh42/multigrid) has no tests and no golden vectors, and its cell-level
+ *   arithmetic lives in gym-minigrid==1.0.3 / gym==0.23.1 (requirements.txt:3-4), which are
+ *   not installed here and cannot be fetched.  The multi-agent logic below follows the
+ *   reference's own files line by line (citations per function); the minigrid pieces
+ *   (Grid.get/set/encode/process_vis, object flags, DIR_TO_VEC, _reward) restate the
+ *   published 1.0.3 algorithm as recorded in SURVEY.md Appendix A.  The one data pin the
+ *   reference tree holds — env rewards logged in v1_final_results_*.json — is checked in
+ *   tests/test_oracle_pins.py.
+ *
+ * Deliberately literal: an object grid, Grid.slice, rotate_left applied dir+1 times, the
+ * two-pass process_vis loops and encode are all executed as the reference executes them, so
+ * that the HIP kernels' closed forms (view->world index, bitmask visibility) are checked
+ * against the original algorithm and not against themselves.
+ *
+ * All paths are relative to /root/reference/.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#define MAXW 32
+#define MAXA 8
+#define MAXV 9
+
+enum { T_NONE = 0, T_EMPTY = 1, T_WALL = 2, T_FLOOR = 3, T_DOOR = 4, T_KEY = 5, T_BALL = 6,
+       T_BOX = 7, T_GOAL = 8, T_LAVA = 9, T_AGENT = 10 };
+enum { C_RED = 0, C_GREEN = 1, C_BLUE = 2, C_PURPLE = 3, C_YELLOW = 4, C_GREY = 5 };
+enum { A_LEFT = 0, A_RIGHT = 1, A_FORWARD = 2, A_PICKUP = 3, A_DROP = 4, A_TOGGLE = 5, A_DONE = 6 };
+
+/* error bits, same values as include/mgrid.h */
+enum { ERR_BAD_ACTION = 1, ERR_BAD_RESPAWN = 2, ERR_BAD_ORDER = 4, ERR_MISSING_DRAW = 8 };
+
+/* One grid object.  type == T_NONE is Python's None.  For agents color = agent_id and
+ * state = dir (Agent.encode, envs/gym_multigrid/multigrid.py:137-139); for doors state is
+ * 0 open / 1 closed / 2 locked (multigrid.py:93). */
+typedef struct { uint8_t type, color, state, pad; } obj_t;
+
+static const obj_t NONE = {T_NONE, 0, 0, 0};
+
+/* gym_minigrid.minigrid.DIR_TO_VEC (consistent with get_view_exts,
+ * multigrid.py:754-769) */
+static const int DIR_TO_VEC[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
+
+typedef struct { obj_t c[MAXW * MAXW]; int w, h; } grid_t;
+
+/* minigrid Grid.get / Grid.set: storage index j*width + i */
+static obj_t grid_get(const grid_t* g, int i, int j) { return g->c[j * g->w + i]; }
+static void grid_set(grid_t* g, int i, int j, obj_t v) { g->c[j * g->w + i] = v; }
+
+/* WorldObj flags */
+static int can_overlap(obj_t o) {
+  return o.type == T_GOAL || o.type == T_LAVA || o.type == T_FLOOR || (o.type == T_DOOR && o.state == 0);
+}
+static int can_pickup(obj_t o) { return o.type == T_KEY || o.type == T_BALL || o.type == T_BOX; }
+static int see_behind(obj_t o) {
+  if (o.type == T_WALL) return 0;
+  if (o.type == T_DOOR) return o.state == 0;
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Philox4x32-10 (Salmon et al., SC'11) — the build's own free-running RNG; it has no
+ * reference counterpart (the reference uses NumPy's MT19937 / PCG64, which replay mode
+ * injects instead).  Counter layout: (env_global_id lo, step index lo, step index hi,
+ * purpose<<28 | agent<<20 | attempt).
+ * ---------------------------------------------------------------------------------------- */
+static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+void mgo_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
+
+enum { P_ORDER = 0, P_RESPAWN = 1, P_SPAWN = 2, P_ACTION = 3 };
+#define MAX_ATTEMPTS 256
+
+static uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+typedef struct mgo_env {
+  int W, H, A, V, max_steps, see_through, competitive, shaping, auto_reset;
+  uint64_t seed, gid;
+  grid_t base;                 /* static layout, restored by every reset (fixed_environment) */
+  grid_t grid;
+  int ax[MAXA], ay[MAXA], adir[MAXA], has_pos[MAXA];
+  obj_t carrying[MAXA];
+  int done[MAXA];
+  int step_count;
+  /* v8 shaper state (v8_robust_ppo.py:127-129) */
+  int sh_has[MAXA]; double sh_dist[MAXA]; int sh_px[MAXA], sh_py[MAXA], sh_stat[MAXA];
+  uint32_t err;
+  /* draw source for place_one_agent during the current call */
+  const int8_t* inj;           /* injected (x,y,dir) per agent, stride 4 bytes, or NULL */
+  int purpose; uint64_t t;
+  /* recorder: what the last step drew, in the layout replay mode injects */
+  uint8_t last_order[MAXA];
+  int8_t last_respawn[MAXA * 4], last_spawn[MAXA * 4];
+} mgo_env;
+
+mgo_env* mgo_create(int W, int H, int A, int V, int max_steps, int see_through, int competitive,
+                    int shaping, int auto_reset, uint64_t seed, uint64_t gid) {
+  if (W < 3 || H < 3 || W > MAXW || H > MAXW || A < 1 || A > MAXA || V < 3 || V > MAXV || !(V & 1)) return NULL;
+  mgo_env* e = (mgo_env*)calloc(1, sizeof(mgo_env));
+  e->W = W; e->H = H; e->A = A; e->V = V; e->max_steps = max_steps; e->see_through = see_through;
+  e->competitive = (A == 1) ? 1 : competitive;      /* multigrid.py:380-381 */
+  e->shaping = shaping; e->auto_reset = auto_reset; e->seed = seed; e->gid = gid;
+  e->base.w = e->grid.w = W; e->base.h = e->grid.h = H;
+  return e;
+}
+void mgo_destroy(mgo_env* e) { free(e); }
+
+/* cells: uint8[W*H*3], [(y*W+x)*3+c]; type 1 (empty) and 0 mean None */
+void mgo_set_map(mgo_env* e, const uint8_t* cells) {
+  for (int y = 0; y < e->H; ++y)
+    for (int x = 0; x < e->W; ++x) {
+      const uint8_t* p = cells + (y * e->W + x) * 3;
+      obj_t o = {p[0], p[1], p[2], 0};
+      if (o.type == T_EMPTY || o.type == T_NONE) o = NONE;
+      grid_set(&e->base, x, y, o);
+    }
+}
+
+/* ---- placement: place_obj / place_one_agent / place_agent_at_pos (multigrid.py:560-675) ---- */
+
+static void draw_candidate(mgo_env* e, int agent, int attempt, int* x, int* y, int* dir) {
+  uint32_t ctr[4] = {(uint32_t)e->gid, (uint32_t)e->t, (uint32_t)(e->t >> 32),
+                     ((uint32_t)e->purpose << 28) | ((uint32_t)agent << 20) | (uint32_t)attempt};
+  uint32_t key[2] = {(uint32_t)e->seed, (uint32_t)(e->seed >> 32)}, r[4];
+  philox4x32_10(ctr, key, r);
+  *x = (int)mulhi32(r[0], (uint32_t)e->W);   /* _rand_int(0, grid.width)  multigrid.py:598-599 */
+  *y = (int)mulhi32(r[1], (uint32_t)e->H);   /* _rand_int(0, grid.height) multigrid.py:600-601 */
+  *dir = (int)(r[2] >> 30);                  /* _rand_int(0, 4)           multigrid.py:666 */
+}
+
+/* place_obj's acceptance test (multigrid.py:603-613): cell must hold nothing, and must not be
+ * any agent's recorded position (agents being placed have agent_pos None, multigrid.py:655). */
+static int cell_free(const mgo_env* e, int x, int y) {
+  if (x < 0 || y < 0 || x >= e->W || y >= e->H) return 0;
+  if (grid_get(&e->grid, x, y).type != T_NONE) return 0;
+  for (int a = 0; a < e->A; ++a)
+    if (e->has_pos[a] && e->ax[a] == x && e->ay[a] == y) return 0;
+  return 1;
+}
+
+/* place_one_agent (multigrid.py:646-661) + place_agent_at_pos (multigrid.py:663-675) */
+static void place_one_agent(mgo_env* e, int a) {
+  e->has_pos[a] = 0;                                   /* multigrid.py:655 */
+  int x = -1, y = -1, dir = 0;
+  if (e->inj) {                                        /* replay: the accepted draw is injected */
+    const int8_t* p = e->inj + 4 * a;
+    x = p[0]; y = p[1]; dir = p[2];
+    if (x < 0) { e->err |= ERR_MISSING_DRAW; x = -1; }
+    else if (!cell_free(e, x, y) || dir < 0 || dir > 3) { e->err |= ERR_BAD_RESPAWN; x = -1; }
+  } else {
+    for (int k = 0; k < MAX_ATTEMPTS; ++k) {           /* while True: multigrid.py:589-619 */
+      int cx, cy, cd;
+      draw_candidate(e, a, k, &cx, &cy, &cd);
+      if (cell_free(e, cx, cy)) { x = cx; y = cy; dir = cd; break; }
+    }
+  }
+  if (x < 0) {
+    /* build-defined fallback so that the GPU loop has an exit condition: first free cell in
+     * storage order, direction 0.  (The reference would loop forever, multigrid.py:644.) */
+    dir = 0;
+    for (int j = 0; j < e->H && x < 0; ++j)
+      for (int i = 0; i < e->W; ++i)
+        if (cell_free(e, i, j)) { x = i; y = j; break; }
+    if (x < 0) { x = 0; y = 0; }
+  }
+  {
+    int8_t* rec = (e->purpose == P_SPAWN ? e->last_spawn : e->last_respawn) + 4 * a;
+    rec[0] = (int8_t)x; rec[1] = (int8_t)y; rec[2] = (int8_t)dir; rec[3] = 0;
+  }
+  e->ax[a] = x; e->ay[a] = y; e->has_pos[a] = 1;       /* multigrid.py:664 */
+  e->adir[a] = dir;                                    /* multigrid.py:665-666 */
+  obj_t ag = {T_AGENT, (uint8_t)a, (uint8_t)dir, 0};   /* multigrid.py:669-675 */
+  grid_set(&e->grid, x, y, ag);
+}
+
+/* ---- observation: gen_obs_grid / slice / rotate_left / process_vis / encode ---- */
+
+typedef struct { obj_t c[MAXV * MAXV]; int w, h; } view_t;
+static obj_t view_get(const view_t* g, int i, int j) { return g->c[j * g->w + i]; }
+static void view_set(view_t* g, int i, int j, obj_t v) { g->c[j * g->w + i] = v; }
+
+/* Grid.slice (multigrid.py:301-319): out of bounds -> minigrid.Wall() (grey) */
+static void grid_slice(const grid_t* g, int top_x, int top_y, int w, int h, view_t* out) {
+  out->w = w; out->h = h;
+  for (int j = 0; j < h; ++j)
+    for (int i = 0; i < w; ++i) {
+      int x = top_x + i, y = top_y + j;
+      obj_t v;
+      if (x >= 0 && x < g->w && y >= 0 && y < g->h) v = grid_get(g, x, y);
+      else { v.type = T_WALL; v.color = C_GREY; v.state = 0; v.pad = 0; }
+      view_set(out, i, j, v);
+    }
+}
+
+/* Grid.rotate_left (multigrid.py:281-299) */
+static void view_rotate_left(const view_t* in, view_t* out) {
+  out->w = in->h; out->h = in->w;
+  for (int i = 0; i < in->w; ++i)
+    for (int j = 0; j < in->h; ++j) {
+      obj_t v = view_get(in, i, j);
+      if (v.type == T_AGENT) {                 /* multigrid.py:290-295 */
+        int d = (int)v.state - 1;
+        if (d < 0) d += 4;
+        v.state = (uint8_t)d;
+      }
+      view_set(out, j, out->h - 1 - i, v);      /* multigrid.py:297 */
+    }
+}
+
+/* minigrid Grid.process_vis — literal two-pass loops */
+static void process_vis(view_t* g, int apx, int apy, uint8_t* mask /* [w*h], index i*h+j */) {
+  int w = g->w, h = g->h;
+  memset(mask, 0, (size_t)(w * h));
+#define M(i, j) mask[(i) * h + (j)]
+  M(apx, apy) = 1;
+  for (int j = h - 1; j >= 0; --j) {
+    for (int i = 0; i < w - 1; ++i) {
+      if (!M(i, j)) continue;
+      obj_t cell = view_get(g, i, j);
+      if (cell.type != T_NONE && !see_behind(cell)) continue;
+      M(i + 1, j) = 1;
+      if (j > 0) { M(i + 1, j - 1) = 1; M(i, j - 1) = 1; }
+    }
+    for (int i = w - 1; i >= 1; --i) {
+      if (!M(i, j)) continue;
+      obj_t cell = view_get(g, i, j);
+      if (cell.type != T_NONE && !see_behind(cell)) continue;
+      M(i - 1, j) = 1;
+      if (j > 0) { M(i - 1, j - 1) = 1; M(i, j - 1) = 1; }
+    }
+  }
+  for (int j = 0; j < h; ++j)
+    for (int i = 0; i < w; ++i)
+      if (!M(i, j)) view_set(g, i, j, NONE);
+#undef M
+}
+/* exported for the exhaustive bitmask-vs-literal test: opaque[i*V+j] != 0 -> wall */
+void mgo_process_vis(int V, const uint8_t* opaque, uint8_t* mask) {
+  view_t g; g.w = g.h = V;
+  for (int i = 0; i < V; ++i)
+    for (int j = 0; j < V; ++j) {
+      obj_t o = NONE;
+      if (opaque[i * V + j]) { o.type = T_WALL; o.color = C_GREY; }
+      view_set(&g, i, j, o);
+    }
+  process_vis(&g, V / 2, V - 1, mask);
+}
+
+/* gen_obs_grid (multigrid.py:997-1035) + gen_agent_obs (multigrid.py:1069-1083) +
+ * minigrid Grid.encode.  image: uint8[V*V*3] indexed [(i*V+j)*3+c]. */
+static void gen_agent_obs(const mgo_env* e, int a, uint8_t* image, uint8_t* direction) {
+  int V = e->V, top_x, top_y;
+  /* get_view_exts (multigrid.py:743-776) */
+  switch (e->adir[a]) {
+    case 0: top_x = e->ax[a];             top_y = e->ay[a] - V / 2;     break;
+    case 1: top_x = e->ax[a] - V / 2;     top_y = e->ay[a];             break;
+    case 2: top_x = e->ax[a] - V + 1;     top_y = e->ay[a] - V / 2;     break;
+    default: top_x = e->ax[a] - V / 2;    top_y = e->ay[a] - V + 1;     break;
+  }
+  view_t g0, g1;
+  grid_slice(&e->grid, top_x, top_y, V, V, &g0);                 /* multigrid.py:1012-1013 */
+  view_t* cur = &g0; view_t* nxt = &g1;
+  for (int k = 0; k < e->adir[a] + 1; ++k) {                     /* multigrid.py:1015-1016 */
+    view_rotate_left(cur, nxt);
+    view_t* t = cur; cur = nxt; nxt = t;
+  }
+  uint8_t mask[MAXV * MAXV];
+  if (!e->see_through) process_vis(cur, V / 2, V - 1, mask);     /* multigrid.py:1020-1022 */
+  else memset(mask, 1, (size_t)(V * V));                         /* multigrid.py:1024 */
+  /* multigrid.py:1029-1033: own cell <- carried object or None, after process_vis */
+  view_set(cur, V / 2, V - 1, e->carrying[a]);
+  /* Grid.encode(vis_mask) */
+  for (int i = 0; i < V; ++i)
+    for (int j = 0; j < V; ++j) {
+      uint8_t* p = image + (i * V + j) * 3;
+      if (!mask[i * V + j]) { p[0] = p[1] = p[2] = 0; continue; }   /* unseen */
+      obj_t v = view_get(cur, i, j);
+      if (v.type == T_NONE) { p[0] = T_EMPTY; p[1] = 0; p[2] = 0; }
+      else { p[0] = v.type; p[1] = v.color; p[2] = v.state; }
+    }
+  *direction = (uint8_t)e->adir[a];                               /* multigrid.py:1083 */
+}
+
+/* ---- reset (multigrid.py:466-501; cluttered.py:25-40, 55-63) ---- */
+
+static void clear_shaper(mgo_env* e) {                /* v8_robust_ppo.py:227-229 */
+  for (int a = 0; a < e->A; ++a) { e->sh_has[a] = 0; e->sh_dist[a] = 0.0; e->sh_px[a] = e->sh_py[a] = 0; e->sh_stat[a] = 0; }
+}
+
+static void do_reset(mgo_env* e, const int8_t* spawn, uint64_t t) {
+  for (int a = 0; a < e->A; ++a) { e->has_pos[a] = 0; e->done[a] = 0; }   /* multigrid.py:471-473 */
+  e->grid = e->base;                                   /* _gen_grid with the fixed seed */
+  e->inj = spawn; e->purpose = P_SPAWN; e->t = t;
+  for (int a = 0; a < e->A; ++a) place_one_agent(e, a); /* cluttered.py:61-63 */
+  for (int a = 0; a < e->A; ++a) e->carrying[a] = NONE; /* multigrid.py:490 */
+  e->step_count = 0;                                    /* multigrid.py:493 */
+  clear_shaper(e);
+}
+
+void mgo_reset(mgo_env* e, const int8_t* spawn /* [A][4] or NULL */, uint64_t t) { do_reset(e, spawn, t); }
+
+void mgo_get_obs(const mgo_env* e, uint8_t* image /* [A][V*V*3] */, uint8_t* dir /* [A] */) {
+  for (int a = 0; a < e->A; ++a) gen_agent_obs(e, a, image + a * e->V * e->V * 3, dir + a);
+}
+
+/* ---- step (multigrid.py:815-995) ---- */
+
+/* agent_is_done (multigrid.py:815-832) */
+static void agent_is_done(mgo_env* e, int a) {
+  grid_set(&e->grid, e->ax[a], e->ay[a], NONE);         /* multigrid.py:817-819 */
+  e->done[a] = 1;                                       /* multigrid.py:821 */
+  if (e->carrying[a].type != T_NONE) {
+    /* multigrid.py:827-829: place_obj(carrying) — needs its own draws; no static-map env can
+     * carry anything, so this branch is unreachable in the current scope. */
+    e->err |= ERR_MISSING_DRAW;
+    e->carrying[a] = NONE;
+  }
+  place_one_agent(e, a);                                /* multigrid.py:832 */
+}
+
+/* move_agent (multigrid.py:834-847) */
+static void move_agent(mgo_env* e, int a, int nx, int ny) {
+  obj_t ag = grid_get(&e->grid, e->ax[a], e->ay[a]);
+  grid_set(&e->grid, e->ax[a], e->ay[a], NONE);
+  e->ax[a] = nx; e->ay[a] = ny;
+  grid_set(&e->grid, nx, ny, ag);                       /* overwrites whatever was there */
+}
+
+/* rotate_agent (multigrid.py:849-858) */
+static void rotate_agent(mgo_env* e, int a) {
+  obj_t ag = grid_get(&e->grid, e->ax[a], e->ay[a]);
+  ag.state = (uint8_t)e->adir[a];
+  grid_set(&e->grid, e->ax[a], e->ay[a], ag);
+}
+
+/* _forward (multigrid.py:906-924) */
+static int forward(mgo_env* e, int a, int fx, int fy) {
+  obj_t fwd = grid_get(&e->grid, fx, fy);
+  int blocking = 0;
+  for (int b = 0; b < e->A; ++b)
+    if (b != a && e->ax[b] == fx && e->ay[b] == fy) blocking = 1;
+  if (!blocking) {
+    if (fwd.type == T_GOAL) agent_is_done(e, a);
+    else if (fwd.type == T_LAVA) agent_is_done(e, a);
+    else if (fwd.type == T_NONE || can_overlap(fwd)) move_agent(e, a, fx, fy);
+    return 1;
+  }
+  return 0;
+}
+
+/* MiniGridEnv._reward */
+static double env_reward(const mgo_env* e) {
+  return 1 - 0.9 * ((double)e->step_count / (double)e->max_steps);
+}
+double mgo_reward_value(int step_count, int max_steps) { return 1 - 0.9 * ((double)step_count / (double)max_steps); }
+
+/* step_one_agent (multigrid.py:860-904) */
+static double step_one_agent(mgo_env* e, int action, int a) {
+  double reward = 0;
+  /* front_pos (multigrid.py:697-703), computed before the action */
+  int fx = e->ax[a] + DIR_TO_VEC[e->adir[a]][0], fy = e->ay[a] + DIR_TO_VEC[e->adir[a]][1];
+  /* agents live strictly inside the border wall, so (fx,fy) is always on the grid */
+  if (action == A_LEFT) {
+    e->adir[a] -= 1;
+    if (e->adir[a] < 0) e->adir[a] += 4;
+    rotate_agent(e, a);
+  } else if (action == A_RIGHT) {
+    e->adir[a] = (e->adir[a] + 1) % 4;
+    rotate_agent(e, a);
+  } else if (action == A_FORWARD) {
+    int ok = forward(e, a, fx, fy);
+    obj_t fwd = grid_get(&e->grid, fx, fy);             /* re-read after the move, :881 */
+    if (ok && fwd.type == T_GOAL) reward = env_reward(e);
+  } else if (action == A_PICKUP) {                      /* _pickup multigrid.py:926-938 */
+    obj_t fwd = grid_get(&e->grid, fx, fy);
+    if (fwd.type != T_NONE && can_pickup(fwd) && e->carrying[a].type == T_NONE) {
+      e->carrying[a] = fwd;
+      grid_set(&e->grid, fx, fy, NONE);
+    }
+  } else if (action == A_DROP) {                        /* _drop multigrid.py:940-951 */
+    obj_t fwd = grid_get(&e->grid, fx, fy);
+    if (fwd.type == T_NONE && e->carrying[a].type != T_NONE) {
+      grid_set(&e->grid, fx, fy, e->carrying[a]);
+      e->carrying[a] = NONE;
+    }
+  } else if (action == A_TOGGLE) {                      /* _toggle multigrid.py:953-961 */
+    obj_t fwd = grid_get(&e->grid, fx, fy);
+    if (fwd.type == T_DOOR) {                           /* Door.toggle multigrid.py:112-122 */
+      if (fwd.state == 2) {
+        if (e->carrying[a].type == T_KEY && e->carrying[a].color == fwd.color) { fwd.state = 0; grid_set(&e->grid, fx, fy, fwd); }
+      } else {
+        fwd.state = fwd.state == 0 ? 1 : 0;
+        grid_set(&e->grid, fx, fy, fwd);
+      }
+    } else if (fwd.type == T_BOX) {
+      grid_set(&e->grid, fx, fy, NONE);                 /* Box.toggle with empty contents */
+    }
+  } else if (action == A_DONE) {
+    /* no-op, multigrid.py:898-899 */
+  } else {
+    e->err |= ERR_BAD_ACTION;                           /* assert False, multigrid.py:902 */
+  }
+  return reward;
+}
+
+/* get_goal_position (v8_robust_ppo.py:159-169) */
+static void goal_position(const mgo_env* e, int* gx, int* gy) {
+  for (int i = 0; i < e->W; ++i)
+    for (int j = 0; j < e->H; ++j)
+      if (grid_get(&e->grid, i, j).type == T_GOAL) { *gx = i; *gy = j; return; }
+  *gx = 13; *gy = 13;
+}
+void mgo_goal(const mgo_env* e, int* gx, int* gy) { goal_position(e, gx, gy); }
+
+/* shape_rewards (v8_robust_ppo.py:171-220), float64 with one rounding per Python operation */
+static void shape_rewards(mgo_env* e, const double* orig, const int* actions, double* shaped) {
+  int gx, gy;
+  goal_position(e, &gx, &gy);
+  for (int i = 0; i < e->A; ++i) {
+    int px = e->ax[i], py = e->ay[i], action = actions[i];
+    if (orig[i] > 0) {                                   /* v8:181-186 */
+      shaped[i] = 5.0;
+      e->sh_has[i] = 0; e->sh_stat[i] = 0;
+      continue;
+    }
+    volatile double reward = 0.0;                        /* volatile: forbid FMA contraction */
+    long dx = px - gx, dy = py - gy;
+    double current_dist = sqrt((double)(dx * dx + dy * dy));   /* np.linalg.norm, v8:192 */
+    if (e->sh_has[i]) {                                  /* v8:193-195 */
+      volatile double dist_change = e->sh_dist[i] - current_dist;
+      volatile double term = dist_change * 0.2;
+      reward = reward + term;
+    }
+    int had_prev = e->sh_has[i];
+    e->sh_dist[i] = current_dist;                        /* v8:196 */
+    if (had_prev) {                                      /* v8:199-206 (prev_positions set iff prev_distances set) */
+      if (px == e->sh_px[i] && py == e->sh_py[i]) {
+        e->sh_stat[i] += 1;
+        if (e->sh_stat[i] > 3) reward = reward - 0.05;
+      } else {
+        e->sh_stat[i] = 0;
+        reward = reward + 0.02;
+      }
+    }
+    if (action == 2) reward = reward + 0.02;             /* v8:209-212 */
+    else if (action == 0 || action == 1) reward = reward + 0.01;
+    double r = reward;
+    if (-0.2 > r) r = -0.2;                              /* max(reward, -0.2), v8:215 */
+    shaped[i] = r;
+    e->sh_px[i] = px; e->sh_py[i] = py; e->sh_has[i] = 1; /* v8:218 */
+  }
+}
+
+/* MultiGridEnv.step (multigrid.py:963-995) followed by the v8 shaper (v8:239-243) and the
+ * build's auto-reset.  order == NULL -> Philox Fisher-Yates; respawn/reset_spawn == NULL ->
+ * Philox rejection sampling.  t = step index (Philox counter).  Outputs may be NULL. */
+void mgo_step(mgo_env* e, const int* actions, const uint8_t* order, const int8_t* respawn,
+              const int8_t* reset_spawn, uint64_t t, uint8_t* image, uint8_t* dir, double* reward,
+              double* env_rew, uint8_t* done_out) {
+  int A = e->A, ord[MAXA];
+  e->step_count += 1;                                    /* multigrid.py:968 */
+  double rewards[MAXA];
+  for (int a = 0; a < A; ++a) rewards[a] = 0;            /* multigrid.py:970 */
+  if (order) {
+    unsigned seen = 0;
+    for (int k = 0; k < A; ++k) { ord[k] = order[k]; if (ord[k] < A) seen |= 1u << ord[k]; }
+    if (seen != (1u << A) - 1) { e->err |= ERR_BAD_ORDER; for (int k = 0; k < A; ++k) ord[k] = k; }
+  } else {
+    /* uniform permutation; same shape as np.random.shuffle's Fisher-Yates (multigrid.py:973-974) */
+    uint32_t ctr[4] = {(uint32_t)e->gid, (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)P_ORDER << 28};
+    uint32_t key[2] = {(uint32_t)e->seed, (uint32_t)(e->seed >> 32)}, r[4];
+    philox4x32_10(ctr, key, r);
+    for (int k = 0; k < A; ++k) ord[k] = k;
+    for (int i = A - 1, w = 0; i >= 1; --i, ++w) {
+      int j = (int)mulhi32(r[w & 3], (uint32_t)(i + 1));
+      int tmp = ord[i]; ord[i] = ord[j]; ord[j] = tmp;
+    }
+  }
+  e->inj = respawn; e->purpose = P_RESPAWN; e->t = t;
+  for (int a = 0; a < A; ++a) {
+    e->last_order[a] = (uint8_t)ord[a];
+    e->last_respawn[4 * a] = -1; e->last_respawn[4 * a + 1] = -1; e->last_respawn[4 * a + 2] = 0; e->last_respawn[4 * a + 3] = 0;
+  }
+  for (int k = 0; k < A; ++k) {                          /* multigrid.py:977-978 */
+    int a = ord[k];
+    rewards[a] = step_one_agent(e, actions[a], a);
+  }
+  int collective_done = 0;                               /* multigrid.py:986-993 */
+  if (e->competitive) {
+    int s = 0;
+    for (int a = 0; a < A; ++a) s += e->done[a];
+    collective_done = s >= 1;
+  }
+  if (e->step_count >= e->max_steps) collective_done = 1;
+
+  double shaped[MAXA];
+  if (e->shaping == 1) shape_rewards(e, rewards, actions, shaped);
+  else for (int a = 0; a < A; ++a) shaped[a] = rewards[a];
+
+  if (collective_done && e->auto_reset) do_reset(e, reset_spawn, t);
+
+  if (image && dir) mgo_get_obs(e, image, dir);          /* multigrid.py:980 */
+  for (int a = 0; a < A; ++a) {
+    if (reward) reward[a] = shaped[a];
+    if (env_rew) env_rew[a] = rewards[a];
+  }
+  if (done_out) *done_out = (uint8_t)collective_done;
+}
+
+/* Philox action draw for synthetic rollouts: uniform in [0,6] */
+void mgo_random_actions(const mgo_env* e, uint64_t t, int* actions) {
+  uint32_t ctr[4] = {(uint32_t)e->gid, (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)P_ACTION << 28};
+  uint32_t key[2] = {(uint32_t)e->seed, (uint32_t)(e->seed >> 32)}, r[4];
+  philox4x32_10(ctr, key, r);
+  for (int a = 0; a < e->A; ++a) actions[a] = (int)mulhi32(r[a & 3], 7u);
+}
+
+/* state getters (same packing as include/mgrid.h mg_buffers) */
+uint32_t mgo_agent_state(const mgo_env* e, int a) {
+  uint32_t c = e->carrying[a].type == T_NONE ? 0u : (uint32_t)(e->carrying[a].type * 8 + e->carrying[a].color);
+  return (uint32_t)e->ax[a] | ((uint32_t)e->ay[a] << 8) | ((uint32_t)e->adir[a] << 16) | (c << 24);
+}
+uint32_t mgo_shaper_state(const mgo_env* e, int a) {
+  if (!e->sh_has[a]) return (uint32_t)e->sh_stat[a] << 17;
+  return (uint32_t)e->sh_px[a] | ((uint32_t)e->sh_py[a] << 8) | (1u << 16) | ((uint32_t)e->sh_stat[a] << 17);
+}
+uint32_t mgo_step_state(const mgo_env* e) {
+  uint32_t d = 0;
+  for (int a = 0; a < e->A; ++a) d |= (uint32_t)(e->done[a] != 0) << a;
+  return (uint32_t)e->step_count | (d << 16);
+}
+/* what the last step/reset drew: order[A], respawn[A][4], spawn[A][4] */
+void mgo_last_draws(const mgo_env* e, uint8_t* order, int8_t* respawn, int8_t* spawn) {
+  if (order) memcpy(order, e->last_order, (size_t)e->A);
+  if (respawn) memcpy(respawn, e->last_respawn, (size_t)e->A * 4);
+  if (spawn) memcpy(spawn, e->last_spawn, (size_t)e->A * 4);
+}
+uint32_t mgo_errors(mgo_env* e) { uint32_t r = e->err; e->err = 0; return r; }
+void mgo_get_grid(const mgo_env* e, uint8_t* cells /* [W*H*3], None -> (1,0,0) */) {
+  for (int y = 0; y < e->H; ++y)
+    for (int x = 0; x < e->W; ++x) {
+      obj_t o = grid_get(&e->grid, x, y);
+      uint8_t* p = cells + (y * e->W + x) * 3;
+      if (o.type == T_NONE) { p[0] = T_EMPTY; p[1] = p[2] = 0; } else { p[0] = o.type; p[1] = o.color; p[2] = o.state; }
+    }
+}
+/* test hook: put an object on the live grid (used by DoorKey-style known-answer tests) */
+void mgo_put_obj(mgo_env* e, int x, int y, int type, int color, int state) {
+  obj_t o = {(uint8_t)type, (uint8_t)color, (uint8_t)state, 0};
+  if (type == T_EMPTY) o = NONE;
+  grid_set(&e->grid, x, y, o);
+}
+void mgo_set_step_count(mgo_env* e, int s) { e->step_count = s; }
+
+/* ------------------------------------------------------------------------------------------
+ * Batched drivers over the product's agent-major layouts (include/mgrid.h), so tests can
+ * compare device arrays with oracle arrays element for element.  stride = env_stride.
+ * ---------------------------------------------------------------------------------------- */
+void mgo_batch_reset(mgo_env** envs, int64_t n, int64_t stride, const uint8_t* mask,
+                     const int8_t* spawn /* [A][stride][4] or NULL */, uint64_t t,
+                     uint8_t* image, uint8_t* dir) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    mgo_env* e = envs[i];
+    if (mask && !mask[i]) continue;
+    int8_t sp[MAXA * 4];
+    if (spawn) for (int a = 0; a < e->A; ++a) memcpy(sp + 4 * a, spawn + ((int64_t)a * stride + i) * 4, 4);
+    do_reset(e, spawn ? sp : NULL, t);
+    if (image && dir) {
+      uint8_t img[MAXA * MAXV * MAXV * 3], d[MAXA];
+      int cb = e->V * e->V * 3;
+      mgo_get_obs(e, img, d);
+      for (int a = 0; a < e->A; ++a) {
+        memcpy(image + ((int64_t)a * stride + i) * cb, img + a * cb, (size_t)cb);
+        dir[(int64_t)a * stride + i] = d[a];
+      }
+    }
+  }
+}
+
+void mgo_batch_step(mgo_env** envs, int64_t n, int64_t stride, const uint8_t* actions /* [A][stride] or NULL -> Philox */,
+                    const uint8_t* order, const int8_t* respawn, const int8_t* reset_spawn, uint64_t t,
+                    uint8_t* image, uint8_t* dir, double* reward, double* env_rew, uint8_t* done,
+                    uint8_t* actions_out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    mgo_env* e = envs[i];
+    int A = e->A, act[MAXA], cb = e->V * e->V * 3;
+    uint8_t ord[MAXA]; int8_t rs[MAXA * 4], sp[MAXA * 4];
+    if (actions) for (int a = 0; a < A; ++a) act[a] = actions[(int64_t)a * stride + i];
+    else mgo_random_actions(e, t, act);
+    if (actions_out) for (int a = 0; a < A; ++a) actions_out[(int64_t)a * stride + i] = (uint8_t)act[a];
+    if (order) for (int k = 0; k < A; ++k) ord[k] = order[(int64_t)k * stride + i];
+    if (respawn) for (int a = 0; a < A; ++a) memcpy(rs + 4 * a, respawn + ((int64_t)a * stride + i) * 4, 4);
+    if (reset_spawn) for (int a = 0; a < A; ++a) memcpy(sp + 4 * a, reset_spawn + ((int64_t)a * stride + i) * 4, 4);
+    uint8_t img[MAXA * MAXV * MAXV * 3], d[MAXA], dn;
+    double rw[MAXA], er[MAXA];
+    mgo_step(e, act, order ? ord : NULL, respawn ? rs : NULL, reset_spawn ? sp : NULL, t,
+             image ? img : NULL, image ? d : NULL, rw, er, &dn);
+    for (int a = 0; a < A; ++a) {
+      int64_t o = (int64_t)a * stride + i;
+      if (image) { memcpy(image + o * cb, img + a * cb, (size_t)cb); dir[o] = d[a]; }
+      if (reward) reward[o] = rw[a];
+      if (env_rew) env_rew[o] = er[a];
+    }
+    if (done) done[i] = dn;
+  }
+}

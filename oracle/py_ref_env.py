@@ -1,0 +1,514 @@
+"""Pure-Python, object-per-cell restatement of the reference's step path.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py) — "restatement, not cxh42 code".  Two uses:
+  * an independent second opinion for oracle/mg_oracle.c (tests/test_oracle_cross.py);
+  * bench.py's cpu_baseline: its cost structure matches the reference's CPU path (a Python list
+    of heap objects, Grid.slice -> rotate_left x (dir+1) -> process_vis -> encode per agent per
+    step), so its speed is representative of `gym_multigrid` on the same cores.
+Parity status: unpinned except `_reward` (see mg_oracle.c header).
+
+Follows, behaviour for behaviour (paths relative to /root/reference):
+  envs/gym_multigrid/multigrid.py:466-501, 560-703, 743-776, 815-1083
+  envs/gym_multigrid/multigrid_envs/cluttered.py:25-63
+  v8_robust_ppo.py:159-220
+and gym-minigrid 1.0.3's Grid/WorldObj/process_vis/encode/_reward.
+"""
+import numpy as np
+
+OBJ_IDX = {'unseen': 0, 'empty': 1, 'wall': 2, 'floor': 3, 'door': 4, 'key': 5, 'ball': 6,
+           'box': 7, 'goal': 8, 'lava': 9, 'agent': 10}
+IDX_OBJ = {v: k for k, v in OBJ_IDX.items()}
+COLOR_IDX = {'red': 0, 'green': 1, 'blue': 2, 'purple': 3, 'yellow': 4, 'grey': 5}
+IDX_COLOR = {v: k for k, v in COLOR_IDX.items()}
+HEADING = (np.array((1, 0)), np.array((0, 1)), np.array((-1, 0)), np.array((0, -1)))
+LEFT, RIGHT, FORWARD, PICKUP, DROP, TOGGLE, DONE = range(7)
+
+
+class Thing:
+  """A grid object (minigrid WorldObj)."""
+  overlap = False
+  pickable = False
+  opaque = False
+
+  def __init__(self, kind, color='grey'):
+    self.kind = kind
+    self.color = color
+
+  def can_overlap(self):
+    return self.overlap
+
+  def can_pickup(self):
+    return self.pickable
+
+  def see_behind(self):
+    return not self.opaque
+
+  def toggle(self, env, pos, carrying=None):
+    return False
+
+  def encode(self):
+    return (OBJ_IDX[self.kind], COLOR_IDX[self.color], 0)
+
+
+class Wall(Thing):
+  opaque = True
+
+  def __init__(self, color='grey'):
+    super().__init__('wall', color)
+
+
+class Goal(Thing):
+  overlap = True
+
+  def __init__(self):
+    super().__init__('goal', 'green')
+
+
+class Lava(Thing):
+  overlap = True
+
+  def __init__(self):
+    super().__init__('lava', 'red')
+
+
+class Floor(Thing):
+  overlap = True
+
+  def __init__(self, color='blue'):
+    super().__init__('floor', color)
+
+
+class Key(Thing):
+  pickable = True
+
+  def __init__(self, color='blue'):
+    super().__init__('key', color)
+
+
+class Ball(Thing):
+  pickable = True
+
+  def __init__(self, color='blue'):
+    super().__init__('ball', color)
+
+
+class Door(Thing):
+  """multigrid.py:109-122 on top of minigrid.Door."""
+
+  def __init__(self, color, is_open=False, is_locked=False):
+    super().__init__('door', color)
+    self.is_open = is_open
+    self.is_locked = is_locked
+
+  def can_overlap(self):
+    return self.is_open
+
+  def see_behind(self):
+    return self.is_open
+
+  def toggle(self, env, pos, carrying=None):
+    if self.is_locked:
+      if isinstance(carrying, Key) and carrying.color == self.color:
+        self.is_locked = False
+        self.is_open = True
+        return True
+      return False
+    self.is_open = not self.is_open
+    return True
+
+  def encode(self):
+    state = 0 if self.is_open else (2 if self.is_locked else 1)
+    return (OBJ_IDX['door'], COLOR_IDX[self.color], state)
+
+
+class AgentObj(Thing):
+  """multigrid.py:125-139."""
+
+  def __init__(self, agent_id, heading):
+    super().__init__('agent')
+    self.agent_id = agent_id
+    self.dir = heading
+
+  def encode(self):
+    return (OBJ_IDX['agent'], self.agent_id, self.dir)
+
+
+def decode_cell(t, c, s):
+  kind = IDX_OBJ[int(t)]
+  if kind in ('empty', 'unseen'):
+    return None
+  if kind == 'wall':
+    return Wall(IDX_COLOR[int(c)])
+  if kind == 'goal':
+    return Goal()
+  if kind == 'lava':
+    return Lava()
+  if kind == 'floor':
+    return Floor(IDX_COLOR[int(c)])
+  if kind == 'key':
+    return Key(IDX_COLOR[int(c)])
+  if kind == 'ball':
+    return Ball(IDX_COLOR[int(c)])
+  if kind == 'door':
+    return Door(IDX_COLOR[int(c)], s == 0, s == 2)
+  raise ValueError(kind)
+
+
+class CellGrid:
+  """minigrid Grid + the multi-agent overrides (multigrid.py:281-319)."""
+
+  def __init__(self, width, height):
+    self.width = width
+    self.height = height
+    self.cells = [None] * (width * height)
+
+  def get(self, i, j):
+    return self.cells[j * self.width + i]
+
+  def set(self, i, j, v):
+    self.cells[j * self.width + i] = v
+
+  def slice(self, top_x, top_y, width, height):
+    out = CellGrid(width, height)
+    for j in range(height):
+      for i in range(width):
+        x, y = top_x + i, top_y + j
+        if 0 <= x < self.width and 0 <= y < self.height:
+          out.set(i, j, self.get(x, y))
+        else:
+          out.set(i, j, Wall())
+    return out
+
+  def rotate_left(self):
+    out = CellGrid(self.height, self.width)
+    for i in range(self.width):
+      for j in range(self.height):
+        v = self.get(i, j)
+        if v is not None and v.kind == 'agent':
+          v = AgentObj(v.agent_id, (v.dir - 1) % 4)
+        out.set(j, out.height - 1 - i, v)
+    return out
+
+  def process_vis(self, agent_pos):
+    w, h = self.width, self.height
+    mask = np.zeros((w, h), dtype=bool)
+    mask[agent_pos[0], agent_pos[1]] = True
+    for j in reversed(range(h)):
+      for i in range(w - 1):
+        if not mask[i, j]:
+          continue
+        cell = self.get(i, j)
+        if cell and not cell.see_behind():
+          continue
+        mask[i + 1, j] = True
+        if j > 0:
+          mask[i + 1, j - 1] = True
+          mask[i, j - 1] = True
+      for i in reversed(range(1, w)):
+        if not mask[i, j]:
+          continue
+        cell = self.get(i, j)
+        if cell and not cell.see_behind():
+          continue
+        mask[i - 1, j] = True
+        if j > 0:
+          mask[i - 1, j - 1] = True
+          mask[i, j - 1] = True
+    for j in range(h):
+      for i in range(w):
+        if not mask[i, j]:
+          self.set(i, j, None)
+    return mask
+
+  def encode(self, vis_mask=None):
+    if vis_mask is None:
+      vis_mask = np.ones((self.width, self.height), dtype=bool)
+    arr = np.zeros((self.width, self.height, 3), dtype='uint8')
+    for i in range(self.width):
+      for j in range(self.height):
+        if vis_mask[i, j]:
+          v = self.get(i, j)
+          if v is None:
+            arr[i, j, 0] = OBJ_IDX['empty']
+          else:
+            arr[i, j, :] = v.encode()
+    return arr
+
+
+class PyRefEnv:
+  """Object-style MultiGrid env over a fixed layout (ClutteredMultiGridFixed15x15 shape).
+
+  `draws` hooks replace the reference's two RNG streams: `order_fn()` returns the acting order
+  (np.random.shuffle, multigrid.py:973-974) and `rand_int(lo, hi)` is `_rand_int`.
+  """
+
+  def __init__(self, cells, n_agents=3, view_size=5, max_steps=100, see_through_walls=False,
+               competitive=False, rand_int=None, order_fn=None, seed=0):
+    self.layout = np.asarray(cells, np.uint8)
+    self.height, self.width = self.layout.shape[:2]
+    self.n_agents = n_agents
+    self.agent_view_size = view_size
+    self.max_steps = max_steps
+    self.see_through_walls = see_through_walls
+    self.competitive = True if n_agents == 1 else competitive
+    self._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+    self._order_rng = np.random.RandomState(seed)
+    self.rand_int = rand_int or (lambda lo, hi: int(self._np_random.integers(lo, hi)))
+    self.order_fn = order_fn or self._shuffled
+    self.agent_pos = [None] * n_agents
+    self.agent_dir = [None] * n_agents
+    self.done = [False] * n_agents
+    self.reset()
+
+  def _shuffled(self):
+    o = np.arange(self.n_agents)
+    self._order_rng.shuffle(o)
+    return o
+
+  # --- reset / placement (multigrid.py:466-501, 560-675) ---
+  def reset(self):
+    self.agent_pos = [None] * self.n_agents
+    self.agent_dir = [None] * self.n_agents
+    self.done = [False] * self.n_agents
+    self.grid = CellGrid(self.width, self.height)
+    for y in range(self.height):
+      for x in range(self.width):
+        self.grid.set(x, y, decode_cell(*self.layout[y, x]))
+    for a in range(self.n_agents):
+      self.place_one_agent(a)
+    self.carrying = [None] * self.n_agents
+    self.step_count = 0
+    return self.gen_obs()
+
+  def place_obj(self, obj):
+    while True:
+      pos = np.array((self.rand_int(0, self.grid.width), self.rand_int(0, self.grid.height)))
+      if self.grid.get(*pos) is not None:
+        continue
+      if any(np.array_equal(pos, p) for p in self.agent_pos):
+        continue
+      break
+    self.grid.set(pos[0], pos[1], obj)
+    return pos
+
+  def place_one_agent(self, agent_id, agent_obj=None):
+    self.agent_pos[agent_id] = None
+    pos = self.place_obj(None)
+    self.agent_pos[agent_id] = pos
+    self.agent_dir[agent_id] = self.rand_int(0, 4)
+    if not agent_obj:
+      agent_obj = AgentObj(agent_id, self.agent_dir[agent_id])
+    else:
+      agent_obj.dir = self.agent_dir[agent_id]
+    self.grid.set(pos[0], pos[1], agent_obj)
+    return pos
+
+  # --- step (multigrid.py:815-995) ---
+  def agent_is_done(self, a):
+    pos = self.agent_pos[a]
+    obj = self.grid.get(pos[0], pos[1])
+    self.grid.set(pos[0], pos[1], None)
+    self.done[a] = True
+    if self.carrying[a]:
+      self.place_obj(self.carrying[a])
+      self.carrying[a] = None
+    self.place_one_agent(a, agent_obj=obj)
+
+  def move_agent(self, a, new_pos):
+    old = self.agent_pos[a]
+    obj = self.grid.get(old[0], old[1])
+    assert obj.agent_id == a
+    self.grid.set(old[0], old[1], None)
+    self.agent_pos[a] = new_pos
+    self.grid.set(new_pos[0], new_pos[1], obj)
+
+  def rotate_agent(self, a):
+    pos = self.agent_pos[a]
+    obj = self.grid.get(pos[0], pos[1])
+    assert obj.agent_id == a
+    obj.dir = self.agent_dir[a]
+
+  def _forward(self, a, fwd_pos):
+    fwd_cell = self.grid.get(*fwd_pos)
+    blocked = False
+    for b in range(self.n_agents):
+      if b != a and np.array_equal(self.agent_pos[b], fwd_pos):
+        blocked = True
+    if blocked:
+      return False
+    if fwd_cell is not None and fwd_cell.kind == 'goal':
+      self.agent_is_done(a)
+    elif fwd_cell is not None and fwd_cell.kind == 'lava':
+      self.agent_is_done(a)
+    elif fwd_cell is None or fwd_cell.can_overlap():
+      self.move_agent(a, fwd_pos)
+    return True
+
+  def _reward(self):
+    return 1 - 0.9 * (self.step_count / self.max_steps)
+
+  def step_one_agent(self, action, a):
+    reward = 0
+    fwd_pos = self.agent_pos[a] + HEADING[self.agent_dir[a]]
+    if action == LEFT:
+      self.agent_dir[a] -= 1
+      if self.agent_dir[a] < 0:
+        self.agent_dir[a] += 4
+      self.rotate_agent(a)
+    elif action == RIGHT:
+      self.agent_dir[a] = (self.agent_dir[a] + 1) % 4
+      self.rotate_agent(a)
+    elif action == FORWARD:
+      ok = self._forward(a, fwd_pos)
+      cell = self.grid.get(*fwd_pos)
+      if ok and cell is not None and cell.kind == 'goal':
+        reward = self._reward()
+    elif action == PICKUP:
+      cell = self.grid.get(*fwd_pos)
+      if cell and cell.can_pickup() and self.carrying[a] is None:
+        self.carrying[a] = cell
+        self.grid.set(fwd_pos[0], fwd_pos[1], None)
+    elif action == DROP:
+      cell = self.grid.get(*fwd_pos)
+      if not cell and self.carrying[a]:
+        self.grid.set(fwd_pos[0], fwd_pos[1], self.carrying[a])
+        self.carrying[a] = None
+    elif action == TOGGLE:
+      cell = self.grid.get(*fwd_pos)
+      if cell:
+        if cell.kind == 'door':
+          cell.toggle(self, fwd_pos, self.carrying[a])
+        else:
+          cell.toggle(self, fwd_pos)
+    elif action == DONE:
+      pass
+    else:
+      raise AssertionError('unknown action')
+    return reward
+
+  def step(self, actions):
+    self.step_count += 1
+    rewards = [0] * self.n_agents
+    for a in self.order_fn():
+      rewards[a] = self.step_one_agent(actions[a], a)
+    obs = self.gen_obs()
+    done = False
+    if self.competitive:
+      done = sum(self.done) >= 1
+    if self.step_count >= self.max_steps:
+      done = True
+    return obs, rewards, done, {}
+
+  # --- observation (multigrid.py:743-776, 997-1083) ---
+  def get_view_exts(self, a):
+    v = self.agent_view_size
+    x, y = self.agent_pos[a]
+    d = self.agent_dir[a]
+    if d == 0:
+      return x, y - v // 2
+    if d == 1:
+      return x - v // 2, y
+    if d == 2:
+      return x - v + 1, y - v // 2
+    return x - v // 2, y - v + 1
+
+  def gen_obs_grid(self, a):
+    v = self.agent_view_size
+    top_x, top_y = self.get_view_exts(a)
+    grid = self.grid.slice(top_x, top_y, v, v)
+    for _ in range(self.agent_dir[a] + 1):
+      grid = grid.rotate_left()
+    if not self.see_through_walls:
+      mask = grid.process_vis((v // 2, v - 1))
+    else:
+      mask = np.ones((v, v), dtype=bool)
+    grid.set(v // 2, v - 1, self.carrying[a] if self.carrying[a] else None)
+    return grid, mask
+
+  def gen_obs(self):
+    images, dirs = [], []
+    for a in range(self.n_agents):
+      grid, mask = self.gen_obs_grid(a)
+      images.append(grid.encode(mask))
+      dirs.append(self.agent_dir[a])
+    return {'image': images, 'direction': dirs}
+
+
+class V8Shaper:
+  """v8_robust_ppo.py:126-129, 159-220, 227-229."""
+
+  def __init__(self, env):
+    self.env = env
+    self.clear()
+
+  def clear(self):
+    n = self.env.n_agents
+    self.prev_distances = [None] * n
+    self.prev_positions = [None] * n
+    self.stationary_count = [0] * n
+
+  def goal_position(self):
+    for i in range(self.env.width):
+      for j in range(self.env.height):
+        c = self.env.grid.get(i, j)
+        if c and c.kind == 'goal':
+          return np.array([i, j])
+    return np.array([13, 13])
+
+  def shape(self, agent_positions, original_rewards, actions):
+    out = []
+    goal = self.goal_position()
+    for i in range(self.env.n_agents):
+      pos = np.array(agent_positions[i])
+      action = actions[i]
+      if original_rewards[i] > 0:
+        out.append(5.0)
+        self.prev_distances[i] = None
+        self.prev_positions[i] = None
+        self.stationary_count[i] = 0
+        continue
+      reward = 0.0
+      dist = np.linalg.norm(pos - goal)
+      if self.prev_distances[i] is not None:
+        reward += (self.prev_distances[i] - dist) * 0.2
+      self.prev_distances[i] = dist
+      if self.prev_positions[i] is not None:
+        if np.array_equal(pos, self.prev_positions[i]):
+          self.stationary_count[i] += 1
+          if self.stationary_count[i] > 3:
+            reward -= 0.05
+        else:
+          self.stationary_count[i] = 0
+          reward += 0.02
+      if action == 2:
+        reward += 0.02
+      elif action in [0, 1]:
+        reward += 0.01
+      reward = max(reward, -0.2)
+      out.append(reward)
+      self.prev_positions[i] = pos.copy()
+    return out
+
+
+def random_rollout_rate(cells, seconds=5.0, seed=0, shaping=True):
+  """env-only random-action rollout; returns (agent_steps, wall_seconds).  cpu_baseline leg."""
+  import time
+  env = PyRefEnv(cells, seed=seed)
+  shaper = V8Shaper(env)
+  rng = np.random.RandomState(seed + 1)
+  steps = 0
+  t0 = time.perf_counter()
+  while True:
+    env.reset()
+    shaper.clear()
+    for _ in range(env.max_steps):
+      actions = [int(a) for a in rng.randint(0, 7, size=env.n_agents)]
+      _, rewards, done, _ = env.step(actions)
+      if shaping:
+        shaper.shape([env.agent_pos[i] for i in range(env.n_agents)], rewards, actions)
+      steps += 1
+      if done:
+        break
+    if time.perf_counter() - t0 >= seconds:
+      break
+  return steps * env.n_agents, time.perf_counter() - t0

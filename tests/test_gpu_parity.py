@@ -1,0 +1,213 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Integer/byte buffers must be identical; float64 rewards are compared on their bit patterns.
+BASELINE.json config 2: Cluttered-Fixed-15x15, 3 agents, 4096 envs.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle  # noqa: E402
+
+
+def _need_gpu():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+
+
+def _cmp(env, orc, what=''):
+  n = env.n_envs
+  assert np.array_equal(env.obs_image.cpu().numpy().reshape(env.n_agents, n, -1), orc.obs_image[:, :n]), what + ' obs_image'
+  assert np.array_equal(env.obs_dir.cpu().numpy(), orc.obs_dir[:, :n]), what + ' obs_dir'
+  assert np.array_equal(env.agent_state.cpu().numpy().view(np.uint32), orc.agent_state()[:, :n]), what + ' agent_state'
+  assert np.array_equal(env.step_state.cpu().numpy().view(np.uint32), orc.step_state()[:n]), what + ' step_state'
+
+
+def _cmp_step(env, orc, what=''):
+  n = env.n_envs
+  _cmp(env, orc, what)
+  assert np.array_equal(env.reward.cpu().numpy().view(np.int64), orc.reward[:, :n].view(np.int64)), what + ' reward'
+  if env.env_reward is not None:
+    assert np.array_equal(env.env_reward.cpu().numpy().view(np.int64), orc.env_reward[:, :n].view(np.int64)), what + ' env_reward'
+  assert np.array_equal(env.done.cpu().numpy(), orc.done[:n]), what + ' done'
+  assert np.array_equal(env.shaper_state.cpu().numpy().view(np.uint32), orc.shaper_state()[:, :n]), what + ' shaper_state'
+
+
+def _make(cells, n, **kw):
+  from multigrid_amd.batched import BatchedMultiGrid
+  H, W = cells.shape[:2]
+  okw = dict(W=W, H=H, A=kw.get('n_agents', 3), V=kw.get('view_size', 5), max_steps=kw.get('max_steps', 100),
+             see_through=int(kw.get('see_through_walls', False)), competitive=int(kw.get('competitive', False)),
+             shaping=1 if kw.get('shaping', 'v8') == 'v8' else 0, auto_reset=int(kw.get('auto_reset', True)),
+             seed=kw.get('seed', 0), gid_base=kw.get('env_id_base', 0))
+  env = BatchedMultiGrid(cells, n_envs=n, emit_env_reward=True, **kw)
+  orc = c_oracle.OracleBatch(cells, n, **okw)
+  return env, orc
+
+
+def test_smoke_interface_and_aliasing(cluttered_cells):
+  _need_gpu()
+  env, orc = _make(cluttered_cells, 100, seed=7)
+  env.reset()
+  orc.reset()
+  assert env.check_errors() == 0
+  assert env.obs_image.shape == (3, 100, 5, 5, 3) and env.obs_image.dtype == torch.uint8
+  assert env.reward.dtype == torch.float64
+  _cmp(env, orc, 'reset')
+  env.close()
+
+
+@pytest.mark.parametrize('n,steps,seed', [(4096, 230, 11), (1000, 120, 5), (64, 350, 3), (1, 120, 1)])
+def test_free_running_philox_parity(cluttered_cells, n, steps, seed):
+  """Config 2 free-running: order, respawn, auto-reset spawn all drawn by Philox on both sides;
+  actions uploaded from the host.  Ragged n (not a multiple of 64) covers the tail wave."""
+  _need_gpu()
+  env, orc = _make(cluttered_cells, n, seed=seed)
+  rng = np.random.RandomState(seed)
+  env.reset()
+  orc.reset()
+  _cmp(env, orc, 'reset')
+  touches = 0
+  for t in range(steps):
+    act = rng.randint(0, 7, size=(3, orc.stride)).astype(np.uint8)
+    # bias towards forward so that goal touches and blocking actually happen
+    act[rng.rand(3, orc.stride) < 0.35] = 2
+    env.step(torch.from_numpy(act).to(env.device))
+    orc.step(act)
+    _cmp_step(env, orc, 'step %d' % t)
+    touches += int((orc.env_reward[:, :n] > 0).sum())
+  assert env.check_errors() == 0 and orc.errors() == 0
+  if n >= 1000:
+    assert touches > 0   # the rare branch (goal touch + respawn) was exercised
+
+
+def test_replay_injected_order_and_respawn_parity(cluttered_cells):
+  """Config 2 replay: >= 10k episodes (4096 envs x 3 auto-reset episodes) whose agent orders,
+  respawns and reset spawns were recorded from a CPU run and are injected into the device."""
+  _need_gpu()
+  n, seed = 4096, 21
+  env, orc = _make(cluttered_cells, n, seed=seed)          # recorder: oracle, free-running
+  rng = np.random.RandomState(seed)
+  orc.reset()
+  _, _, spawn0 = orc.last_draws()
+  env.reset(spawn=torch.from_numpy(spawn0).to(env.device))
+  _cmp(env, orc, 'reset')
+  episodes = 0
+  for t in range(300):
+    act = rng.randint(0, 7, size=(3, orc.stride)).astype(np.uint8)
+    act[rng.rand(3, orc.stride) < 0.35] = 2
+    orc.step(act)
+    order, respawn, spawn = orc.last_draws()
+    dev = env.device
+    env.step_replay(torch.from_numpy(act).to(dev), torch.from_numpy(order).to(dev),
+                    torch.from_numpy(respawn).to(dev), torch.from_numpy(spawn).to(dev))
+    _cmp_step(env, orc, 'replay step %d' % t)
+    episodes += int(orc.done[:n].sum())
+  assert episodes >= 10000
+  assert env.check_errors() == 0 and orc.errors() == 0
+
+
+def test_no_auto_reset_terminal_obs_and_no_shaping(cluttered_cells):
+  """Reference behaviour: done at step 100, env keeps its terminal state, rewards unshaped."""
+  _need_gpu()
+  n = 512
+  env, orc = _make(cluttered_cells, n, seed=9, auto_reset=False, shaping=None)
+  rng = np.random.RandomState(9)
+  env.reset()
+  orc.reset()
+  for t in range(103):
+    act = rng.randint(0, 7, size=(3, orc.stride)).astype(np.uint8)
+    env.step(torch.from_numpy(act).to(env.device))
+    orc.step(act)
+    _cmp_step(env, orc, 'step %d' % t)
+    assert bool(env.done.all().item()) == (t >= 99)
+  # masked reset of half the envs
+  mask = (np.arange(n) % 2).astype(np.uint8)
+  env.reset(mask=torch.from_numpy(mask).to(env.device))
+  orc.reset(mask=mask)
+  _cmp(env, orc, 'masked reset')
+
+
+def test_on_device_random_actions_parity(cluttered_cells):
+  _need_gpu()
+  n = 2048
+  env, orc = _make(cluttered_cells, n, seed=1234, env_id_base=5000)
+  env.reset()
+  orc.reset()
+  acts = torch.zeros((3, env.stride), dtype=torch.uint8, device=env.device)
+  oacts = np.zeros((3, orc.stride), np.uint8)
+  for t in range(150):
+    env.step_random(acts)
+    orc.step(None, actions_out=oacts)
+    assert np.array_equal(acts.cpu().numpy()[:, :n], oacts[:, :n])
+    _cmp_step(env, orc, 'random step %d' % t)
+  assert env.check_errors() == 0
+
+
+def test_sharding_invariance(cluttered_cells):
+  """Philox streams are keyed by the global env id: two shards reproduce one big handle."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  whole = BatchedMultiGrid(cluttered_cells, n_envs=256, seed=77)
+  lo = BatchedMultiGrid(cluttered_cells, n_envs=128, seed=77, env_id_base=0)
+  hi = BatchedMultiGrid(cluttered_cells, n_envs=128, seed=77, env_id_base=128)
+  for e in (whole, lo, hi):
+    e.reset()
+  for t in range(120):
+    for e in (whole, lo, hi):
+      e.step_random()
+  torch.cuda.synchronize()
+  assert torch.equal(whole.obs_image[:, :128], lo.obs_image) and torch.equal(whole.obs_image[:, 128:], hi.obs_image)
+  assert torch.equal(whole.reward[:, 128:], hi.reward) and torch.equal(whole.agent_state[:, :128], lo.agent_state)
+
+
+@pytest.mark.parametrize('A,V', [(1, 5), (2, 5), (4, 5), (3, 7), (3, 3)])
+def test_other_shapes(empty_cells, cluttered_cells, A, V):
+  _need_gpu()
+  n = 300
+  env, orc = _make(cluttered_cells, n, seed=A * 10 + V, n_agents=A, view_size=V, max_steps=40)
+  rng = np.random.RandomState(A + V)
+  env.reset()
+  orc.reset()
+  _cmp(env, orc, 'reset')
+  for t in range(90):
+    act = rng.randint(0, 7, size=(A, orc.stride)).astype(np.uint8)
+    act[rng.rand(A, orc.stride) < 0.35] = 2
+    env.step(torch.from_numpy(act).to(env.device))
+    orc.step(act)
+    _cmp_step(env, orc, 'A%d V%d step %d' % (A, V, t))
+  assert env.check_errors() == 0
+
+
+def test_error_reporting(cluttered_cells):
+  _need_gpu()
+  from multigrid_amd import lib
+  env, _ = _make(cluttered_cells, 64, seed=2)
+  env.reset()
+  bad = torch.full((3, env.stride), 9, dtype=torch.uint8, device=env.device)
+  env.step(bad)
+  assert env.check_errors() & lib.ERR_BAD_ACTION
+  assert env.check_errors() == 0
+  # spawn on a wall cell (0,0)
+  sp = torch.zeros((3, env.stride, 4), dtype=torch.int8, device=env.device)
+  env.reset(spawn=sp)
+  assert env.check_errors() & lib.ERR_BAD_RESPAWN
+
+
+def test_refcompat_env_contract():
+  """gym.make(...).reset()/step(list) shape of the reference (v8_robust_ppo.py:224,239,242)."""
+  _need_gpu()
+  import multigrid_amd
+  env = multigrid_amd.make('MultiGrid-Cluttered-Fixed-15x15', shaping=None, auto_reset=False)
+  obs = env.reset()
+  assert set(obs) == {'image', 'direction'} and len(obs['image']) == 3
+  assert obs['image'][0].shape == (5, 5, 3) and obs['image'][0].dtype == np.uint8
+  for s in range(1, 101):
+    obs, rew, done, info = env.step([6, 6, 6])
+    assert isinstance(rew, list) and len(rew) == 3 and info == {}
+    assert done == (s == 100)
+  assert len(env.agent_pos) == 3 and env.agent_pos[0].shape == (2,)
+  env.close()
