@@ -1,0 +1,157 @@
+"""bench.py — env agent-steps/s of the batched MultiGrid step path on N MI355X GPUs.
+
+One "step" = one launch of the fused step kernel over this GPU's whole env batch
+(Cluttered-Fixed-15x15, 3 agents, v8 shaping, auto-reset), with the actions already resident in
+HBM.  Envs shard across ranks with no data-path collective (weak scaling: --envs per GPU).
+Prints one JSON line (see the task contract): value = agent-steps/s over all ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENV_ID = 'MultiGrid-Cluttered-Fixed-15x15'
+B_ALG_PER_ENV_STEP = 308          # algorithmic bytes per env-step (f64 rewards)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ACTION_RING = 16                  # distinct pre-generated action batches cycled through
+
+
+def _cpu_cores():
+  n = os.cpu_count() or 1
+  for k in ('OMP_NUM_THREADS', 'MAX_JOBS'):
+    if os.environ.get(k, '').isdigit():
+      n = min(n, int(os.environ[k]))
+  return max(1, n)
+
+
+def _py_worker(args):
+  cells, seconds, seed = args
+  from oracle import py_ref_env
+  return py_ref_env.random_rollout_rate(cells, seconds=seconds, seed=seed)
+
+
+def cpu_baseline(cells, seconds=12.0):
+  """The reference-style Python env (oracle/py_ref_env.py, a restatement — the reference itself
+  cannot run here or on the box: gym/gym-minigrid are absent) with one process per host core."""
+  import multiprocessing as mp
+  cores = _cpu_cores()
+  ctx = mp.get_context('spawn')
+  with ctx.Pool(cores) as pool:
+    res = pool.map(_py_worker, [(cells, seconds, 100 + i) for i in range(cores)])
+  rate = sum(s / w for s, w in res)
+  out = {'value': rate, 'unit': 'agent-steps/s', 'cores': cores, 'kind': 'port',
+         'sample': 'oracle/py_ref_env.py (object-per-cell Python restatement of gym_multigrid + v8 shaper), '
+                   '%s, random actions, one process per core, %.0f s each' % (ENV_ID, seconds)}
+  # second, stronger CPU figure: the literal C oracle over OpenMP threads
+  try:
+    from oracle import c_oracle
+    n = 4096
+    ob = c_oracle.OracleBatch(cells, n, shaping=1, auto_reset=1, seed=1)
+    ob.reset()
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < 3.0:
+      ob.step(None)
+      steps += 1
+    dt = time.perf_counter() - t0
+    out['c_oracle_value'] = n * 3 * steps / dt
+    out['c_oracle_sample'] = 'oracle/mg_oracle.c, %d envs, OpenMP over %d threads, %.1f s' % (n, cores, dt)
+  except Exception as e:  # the baseline must never take the bench down
+    out['c_oracle_value'] = None
+    out['c_oracle_sample'] = 'failed: %r' % (e,)
+  return out
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=2000)
+  ap.add_argument('--warmup', type=int, default=200)
+  ap.add_argument('--envs', type=int, default=1 << 20, help='envs per GPU (weak scaling)')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-seconds', type=float, default=12.0)
+  args = ap.parse_args()
+
+  import torch
+  import multigrid_amd
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+  else:
+    torch.cuda.set_device(0)
+    local_rank = 0
+  dev = torch.device('cuda', local_rank)
+
+  n = args.envs
+  env = multigrid_amd.make_batched(ENV_ID, n, device=local_rank, seed=0xC0FFEE, env_id_base=rank * n,
+                                   shaping='v8', auto_reset=True)
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(1234 + rank)
+  ring = torch.randint(0, 7, (ACTION_RING, env.n_agents, env.stride), dtype=torch.uint8, device=dev, generator=gen)
+  env.reset()
+
+  def run(k):
+    for i in range(k):
+      env.step(ring[i % ACTION_RING])
+
+  def barrier():
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+      dist.barrier()
+    torch.cuda.synchronize(dev)
+
+  run(args.warmup)
+  barrier()
+  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  ev0.record()
+  run(args.steps)
+  ev1.record()
+  torch.cuda.synchronize(dev)
+  wall = time.perf_counter() - t0
+  if dist is not None:
+    dist.barrier()
+  kernel_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream
+  if dist is not None:
+    tw = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    wall, kernel_ms = float(tw[0]), float(tw[1])
+  errs = env.check_errors()
+
+  if rank == 0:
+    total_agent_steps = float(world) * n * env.n_agents * args.steps
+    achieved = B_ALG_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
+    out = {
+        'metric': 'env agent-steps/sec (whole node) Cluttered-15x15 3 agents; % HBM roofline',
+        'value': total_agent_steps / wall, 'unit': 'agent-steps/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8 obs/state + f64 rewards', 'data': 'synthetic',
+        'config': {'workload': '%s, 3 agents, view 5, v8 shaping + auto-reset fused, %d envs per GPU, '
+                               'uniform random actions resident in HBM' % (ENV_ID, n),
+                   'envs_per_gpu': n, 'global_envs': n * world, 'parallelism': 'env-sharded x%d, no collective in step' % world},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'kernel': 'mg_kernel<3,5>', 'kernel_ms': kernel_ms,
+                     'alg_bytes_per_launch': B_ALG_PER_ENV_STEP * n},
+        'device_errors': errs,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      out['cpu_baseline'] = cpu_baseline(env.cells, args.cpu_seconds)
+    print(json.dumps(out), flush=True)
+  env.close()
+  if dist is not None:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()
