@@ -78,6 +78,7 @@ def main():
 
   import torch
   import multigrid_amd
+  from multigrid_amd import shard
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
@@ -92,8 +93,8 @@ def main():
     local_rank = 0
   dev = torch.device('cuda', local_rank)
 
-  n = args.envs
-  env = multigrid_amd.make_batched(ENV_ID, n, device=local_rank, seed=0xC0FFEE, env_id_base=rank * n,
+  base, n = shard.shard_range(rank, world, args.envs)
+  env = multigrid_amd.make_batched(ENV_ID, n, device=local_rank, seed=0xC0FFEE, env_id_base=base,
                                    shaping='v8', auto_reset=True)
   gen = torch.Generator(device=dev)
   gen.manual_seed(1234 + rank)
@@ -122,18 +123,15 @@ def main():
   if dist is not None:
     dist.barrier()
   kernel_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream
-  if dist is not None:
-    tw = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
-    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-    wall, kernel_ms = float(tw[0]), float(tw[1])
+  wall, value = shard.aggregate(dist, wall, float(n) * env.n_agents * args.steps, world)   # max over ranks
+  kernel_ms, _ = shard.aggregate(dist, kernel_ms, 0.0, world)
   errs = env.check_errors()
 
   if rank == 0:
-    total_agent_steps = float(world) * n * env.n_agents * args.steps
     achieved = B_ALG_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
     out = {
         'metric': 'env agent-steps/sec (whole node) Cluttered-15x15 3 agents; % HBM roofline',
-        'value': total_agent_steps / wall, 'unit': 'agent-steps/s', 'n_gpus': world, 'steps': args.steps,
+        'value': value, 'unit': 'agent-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8 obs/state + f64 rewards', 'data': 'synthetic',
         'config': {'workload': '%s, 3 agents, view 5, v8 shaping + auto-reset fused, %d envs per GPU, '

@@ -58,6 +58,7 @@ def lib():
     L.mgo_reward_value.restype = C.c_double
     L.mgo_reward_value.argtypes = [C.c_int, C.c_int]
     L.mgo_process_vis.argtypes = [C.c_int, u8p, u8p]
+    L.mgo_process_vis_bits.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
     L.mgo_philox.argtypes = [C.POINTER(C.c_uint32)] * 3
     L.mgo_batch_reset.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, i8p, C.c_uint64, u8p, u8p]
     L.mgo_batch_step.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, u8p, i8p, i8p,
@@ -84,6 +85,14 @@ def process_vis(V, opaque):
   m = np.zeros(V * V, np.uint8)
   lib().mgo_process_vis(V, _p(op, u8p), _p(m, u8p))
   return m.reshape(V, V).astype(bool)
+
+
+def process_vis_bits(V, patterns):
+  """Literal process_vis over uint64 bit patterns (bit i*V+j = view cell (i,j) opaque)."""
+  pat = np.ascontiguousarray(patterns, dtype=np.uint64)
+  out = np.zeros_like(pat)
+  lib().mgo_process_vis_bits(V, pat.ctypes.data_as(C.c_void_p), pat.size, out.ctypes.data_as(C.c_void_p))
+  return out
 
 
 def reward_value(step_count, max_steps):

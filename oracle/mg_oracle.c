@@ -263,6 +263,19 @@ void mgo_process_vis(int V, const uint8_t* opaque, uint8_t* mask) {
   process_vis(&g, V / 2, V - 1, mask);
 }
 
+/* batched form over bit patterns: bit (i*V+j) of a pattern = cell (i,j) opaque; same layout out */
+void mgo_process_vis_bits(int V, const uint64_t* patterns, int64_t n, uint64_t* out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t k = 0; k < n; ++k) {
+    uint8_t op[MAXV * MAXV], m[MAXV * MAXV];
+    for (int c = 0; c < V * V; ++c) op[c] = (uint8_t)((patterns[k] >> c) & 1u);
+    mgo_process_vis(V, op, m);
+    uint64_t r = 0;
+    for (int c = 0; c < V * V; ++c) r |= (uint64_t)(m[c] != 0) << c;
+    out[k] = r;
+  }
+}
+
 /* gen_obs_grid (multigrid.py:997-1035) + gen_agent_obs (multigrid.py:1069-1083) +
  * minigrid Grid.encode.  image: uint8[V*V*3] indexed [(i*V+j)*3+c]. */
 static void gen_agent_obs(const mgo_env* e, int a, uint8_t* image, uint8_t* direction) {

@@ -1,0 +1,87 @@
+"""No-GPU checks of the drop-in boundary: libmgrid.so loads and exports every symbol that
+include/mgrid.h declares, struct layouts match the header, and the host logic (registry,
+layouts, argument checking that happens before any HIP call) behaves."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from multigrid_amd import layouts, lib, registry
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+  src = open(os.path.join(ROOT, 'include', 'mgrid.h')).read()
+  src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+  return sorted(set(re.findall(r'\b(mg_[a-z_0-9]+)\s*\(', src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+  names = _declared_functions()
+  assert 'mg_step' in names and 'mg_create' in names and len(names) >= 18
+  L = lib.load()
+  for n in names:
+    assert hasattr(L, n), 'libmgrid.so does not export %s' % n
+  assert sorted(lib.SYMBOLS) == names, 'ctypes binding out of sync with include/mgrid.h'
+
+
+def test_struct_layouts_match_header(tmp_path):
+  """sizeof/offsetof from a C compile of the header == the ctypes mirrors."""
+  src = tmp_path / 'sz.c'
+  src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mgrid.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                 'sizeof(mg_config),offsetof(mg_config,n_envs),offsetof(mg_config,seed),'
+                 'sizeof(mg_buffers),offsetof(mg_buffers,obs_image),offsetof(mg_buffers,step_state));return 0;}')
+  exe = tmp_path / 'sz'
+  import subprocess
+  subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), '-o', str(exe), str(src)])
+  got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+  want = [C.sizeof(lib.MgConfig), lib.MgConfig.n_envs.offset, lib.MgConfig.seed.offset,
+          C.sizeof(lib.MgBuffers), lib.MgBuffers.obs_image.offset, lib.MgBuffers.step_state.offset]
+  assert got == want
+
+
+def test_version_and_error_text_without_gpu():
+  L = lib.load()
+  assert b'gfx950' in L.mg_version()
+  h = C.c_void_p()
+  assert L.mg_create(None, 0, C.byref(h)) == -1 and b'null' in L.mg_last_error()
+  cfg = lib.MgConfig(width=2, height=15, n_agents=3, view_size=5, max_steps=100, n_envs=4, action_dtype=1)
+  assert L.mg_create(C.byref(cfg), 0, C.byref(h)) == -1 and b'width/height' in L.mg_last_error()
+  cfg = lib.MgConfig(width=15, height=15, n_agents=3, view_size=5, max_steps=100, n_envs=0, action_dtype=1)
+  assert L.mg_create(C.byref(cfg), 0, C.byref(h)) == -1
+  cfg = lib.MgConfig(width=15, height=15, n_agents=7, view_size=5, max_steps=100, n_envs=4, action_dtype=1)
+  assert L.mg_create(C.byref(cfg), 0, C.byref(h)) == -4      # MG_EUNSUPPORTED: no such instantiation
+  assert L.mg_step(None, None) == -1
+  assert L.mg_destroy(None) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+  monkeypatch.setattr(lib, '_LIB', None)
+  monkeypatch.setattr(lib, 'LIB_PATH', '/nonexistent/libmgrid.so')
+  with pytest.raises(ImportError, match='no CPU fallback'):
+    lib.load()
+
+
+def test_registry_mirrors_reference_ids():
+  assert 'MultiGrid-Cluttered-Fixed-15x15' in registry.registered_ids()
+  s = registry.spec('MultiGrid-Cluttered-Fixed-15x15')
+  # cluttered.py:50-52
+  assert (s['n_agents'], s['view_size'], s['max_steps']) == (3, 5, 100)
+  with pytest.raises(KeyError):
+    registry.spec('MultiGrid-Nope-v0')
+  with pytest.raises(AssertionError):
+    registry.register('Other-Env', {})
+
+
+def test_layout_generators():
+  g = layouts.cluttered(size=15, n_clutter=25, randomize_goal=True, seed=7)
+  assert int((g[:, :, 0] == 8).sum()) == 1 and int((g[1:-1, 1:-1, 0] == 2).sum()) == 25
+  g2 = layouts.cluttered(size=15, n_clutter=25, randomize_goal=True, seed=7)
+  assert np.array_equal(g, g2)
+  lava = layouts.cluttered(size=9, n_clutter=5, randomize_goal=False, walls_are_lava=True, seed=1)
+  assert int((lava[:, :, 0] == 9).sum()) == 5 and tuple(lava[7, 7]) == (8, 1, 0)
+  e = layouts.empty_bordered(6, 4)
+  assert e.shape == (4, 6, 3) and int((e[:, :, 0] == 2).sum()) == 2 * 6 + 2 * 2

@@ -211,3 +211,62 @@ def test_refcompat_env_contract():
     assert done == (s == 100)
   assert len(env.agent_pos) == 3 and env.agent_pos[0].shape == (2,)
   env.close()
+
+
+def test_golden_replay_fixture():
+  """tests/golden/replay_cluttered_fixed_15x15.npz (recorded from the Python restatement driven
+  with NumPy's PCG64 / MT19937 streams like the reference) replayed through the C ABI: all 24
+  episodes run side by side as 24 envs; obs, rewards, done and agent state must match."""
+  _need_gpu()
+  import os
+  from multigrid_amd.batched import BatchedMultiGrid
+  g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'replay_cluttered_fixed_15x15.npz'))
+  E, T, A = g['actions'].shape
+  env = BatchedMultiGrid(g['cells'], n_envs=E, shaping='v8', auto_reset=False, emit_env_reward=True)
+  dev = env.device
+
+  def am(x):   # [E, A, ...] -> agent-major [A, E, ...]
+    return torch.from_numpy(np.ascontiguousarray(np.swapaxes(x, 0, 1))).to(dev)
+
+  env.reset(spawn=am(g['spawn']))
+  assert np.array_equal(env.obs_image.cpu().numpy(), np.swapaxes(g['obs_image'][:, 0], 0, 1))
+  for t in range(T):
+    env.step_replay(am(g['actions'][:, t]), am(g['order'][:, t]), am(g['respawn'][:, t]))
+    w = 'golden step %d' % t
+    assert np.array_equal(env.obs_image.cpu().numpy(), np.swapaxes(g['obs_image'][:, t + 1], 0, 1)), w
+    assert np.array_equal(env.obs_dir.cpu().numpy(), g['obs_dir'][:, t + 1].T), w
+    assert np.array_equal(env.reward.cpu().numpy().view(np.int64), g['shaped_reward'][:, t].T.copy().view(np.int64)), w
+    assert np.array_equal(env.env_reward.cpu().numpy().view(np.int64), g['env_reward'][:, t].T.copy().view(np.int64)), w
+    assert np.array_equal(env.done.cpu().numpy(), g['done'][:, t]), w
+    assert np.array_equal(env.agent_pos.cpu().numpy().astype(np.uint8), np.swapaxes(g['agent_pos'][:, t + 1], 0, 1)), w
+    assert np.array_equal(env.agent_dir.cpu().numpy().astype(np.uint8), g['agent_dir'][:, t + 1].T), w
+  assert env.check_errors() == 0
+
+
+def test_full_size_properties():
+  """BASELINE config 3 shard (131072 envs): size-independent properties instead of an oracle run —
+  determinism (same seed => identical buffers), step counters in lock-step, every agent on a free
+  cell and no two agents of an env on the same cell, obs own-cell always (1,0,0), done every 100."""
+  _need_gpu()
+  import multigrid_amd
+  n = 131072
+  a = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', n, seed=5)
+  b = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', n, seed=5)
+  a.reset(); b.reset()
+  free = torch.from_numpy((a.cells[:, :, 0] == 1)).to(a.device)
+  for t in range(1, 206):
+    a.step_random(); b.step_random()
+    if t % 100 == 0:
+      assert bool(a.done.all().item())
+      assert int(a.step_count.max().item()) == 0
+    elif t % 41 == 0:
+      assert not bool(a.done.any().item())
+      assert int(a.step_count.min().item()) == t % 100 == int(a.step_count.max().item())
+  assert torch.equal(a.obs_image, b.obs_image) and torch.equal(a.reward, b.reward) and torch.equal(a.agent_state, b.agent_state)
+  pos = a.agent_pos.long()
+  assert bool(free[pos[..., 1], pos[..., 0]].all().item())
+  key = pos[..., 1] * 15 + pos[..., 0]
+  assert not bool(((key[0] == key[1]) | (key[0] == key[2]) | (key[1] == key[2])).any().item())
+  own = a.obs_image[:, :, 2, 4, :].reshape(-1, 3)
+  assert bool((own == torch.tensor([1, 0, 0], dtype=torch.uint8, device=a.device)).all().item())
+  assert a.check_errors() == 0
