@@ -44,6 +44,13 @@ extern "C" {
 #define MG_SHAPING_NONE 0   /* reward = env reward (multigrid.py:881-883) */
 #define MG_SHAPING_V8   1   /* reward = v8_robust_ppo.py:171-220 shaped reward */
 
+/* kernel_path: how the static part of an agent's view is produced.  TABLE = precomputed once
+ * per (free cell, dir) on the host and kept in LDS; GENERIC = slice/rotate/process_vis evaluated
+ * per step from the LDS map.  Both give identical bytes; AUTO takes TABLE when it fits LDS. */
+#define MG_PATH_AUTO    0
+#define MG_PATH_GENERIC 1
+#define MG_PATH_TABLE   2
+
 /* action_dtype */
 #define MG_ACT_U8  1
 #define MG_ACT_I32 4
@@ -85,7 +92,7 @@ typedef struct mg_config {
                                 reference precedent).  0: reference behaviour, caller resets. */
   int32_t action_dtype;      /* MG_ACT_* : element type of the actions array */
   int32_t emit_env_reward;   /* 1: also write the unshaped env reward (mg_buffers.env_reward) */
-  int32_t reserved0;
+  int32_t kernel_path;       /* MG_PATH_AUTO (default), or force MG_PATH_GENERIC / MG_PATH_TABLE */
   int64_t n_envs;            /* envs held by THIS handle (this GPU's shard) */
   int64_t env_id_base;       /* global id of local env 0; Philox streams are keyed by the
                                 global id so results do not depend on the sharding */
@@ -103,10 +110,11 @@ typedef struct mg_buffers {
   double*  reward;       /* [A][env_stride]  rewards[a] (shaped when shaping_kind != NONE) */
   double*  env_reward;   /* [A][env_stride]  unshaped env reward, NULL unless emit_env_reward */
   uint8_t* done;         /* [env_stride]     collective done of the step just taken */
-  uint32_t* agent_state; /* [A][env_stride]  x | y<<8 | dir<<16 | carrying<<24 (post-step,
-                              post-respawn: what v8 reads as env.agent_pos[a], v8:242) */
-  uint32_t* shaper_state;/* [A][env_stride]  prev_x | prev_y<<8 | valid<<16 | stationary<<17 */
-  uint32_t* step_state;  /* [env_stride]     step_count | agent done bits << 16 */
+  uint32_t* env_state;   /* [env_stride][A+1]: words 0..A-1 = one word per agent
+                              x:6 | y:6<<6 | dir:2<<12 | prev_x:6<<14 | prev_y:6<<20 | valid<<26 | stationary:3<<27
+                            (post-step, post-respawn position = what v8 reads as env.agent_pos[a], v8:242;
+                            prev_x, prev_y, valid, stationary = v8 shaper state, v8:127-129, the count saturating at 7
+                            because only "> 3" is ever tested, v8:202); word A = step_count | agent done bits<<16 */
 } mg_buffers;
 
 typedef struct mg_handle mg_handle;
@@ -172,6 +180,10 @@ int mg_check_errors(mg_handle* h, uint32_t* out);
 /* Goal cell the v8 shaper measures distance to (v8_robust_ppo.py:159-169: first 'goal' cell
  * scanning x-major, (13,13) if none). */
 int mg_get_goal(mg_handle* h, int32_t* gx, int32_t* gy);
+
+/* Kernel path actually in use (MG_PATH_GENERIC / MG_PATH_TABLE) and its launch geometry; any
+ * out pointer may be NULL.  No reference counterpart (diagnostics for DESIGN.md / bench.py). */
+int mg_get_launch_info(mg_handle* h, int32_t* path, int32_t* block_threads, int32_t* grid_blocks, int32_t* lds_bytes);
 
 /* Test hook, host only (no GPU call, no reference counterpart): evaluates the kernels' bitmask
  * form of Grid.process_vis on n opacity patterns so that it can be compared

@@ -33,7 +33,7 @@ _ACT = {'u8': (_lib.ACT_U8, torch.uint8), 'i32': (_lib.ACT_I32, torch.int32), 'i
 class BatchedMultiGrid:
   def __init__(self, cells, n_envs, n_agents=3, view_size=5, max_steps=100, see_through_walls=False,
                competitive=False, shaping='v8', auto_reset=True, action_dtype='u8', device=0, seed=0,
-               env_id_base=0, emit_env_reward=False, use_torch_stream=True):
+               env_id_base=0, emit_env_reward=False, use_torch_stream=True, kernel_path='auto'):
     self.L = _lib.load()
     cells = np.ascontiguousarray(cells, dtype=np.uint8)
     assert cells.ndim == 3 and cells.shape[2] == 3, 'cells must be uint8[H, W, 3]'
@@ -46,7 +46,8 @@ class BatchedMultiGrid:
         width=self.width, height=self.height, n_agents=n_agents, view_size=view_size, max_steps=max_steps,
         see_through_walls=int(see_through_walls), competitive=int(competitive),
         shaping_kind={None: 0, 'none': 0, 'v8': 1}[shaping], auto_reset=int(auto_reset),
-        action_dtype=self.act_code, emit_env_reward=int(emit_env_reward), reserved0=0,
+        action_dtype=self.act_code, emit_env_reward=int(emit_env_reward),
+        kernel_path={'auto': 0, 'generic': 1, 'table': 2}[kernel_path],
         n_envs=n_envs, env_id_base=env_id_base, seed=seed)
     self.h = C.c_void_p()
     _lib.check(self.L.mg_create(C.byref(cfg), self.device_index, C.byref(self.h)))
@@ -66,18 +67,14 @@ class BatchedMultiGrid:
     self._reward = _alias(b.reward, (A, S), '<f8', dev)
     self._env_reward = _alias(b.env_reward, (A, S), '<f8', dev) if b.env_reward else None
     self._done = _alias(b.done, (S,), '|u1', dev)
-    self._agent_state = _alias(b.agent_state, (A, S), '<i4', dev)
-    self._shaper_state = _alias(b.shaper_state, (A, S), '<i4', dev)
-    self._step_state = _alias(b.step_state, (S,), '<i4', dev)
+    self._env_state = _alias(b.env_state, (S, A + 1), '<i4', dev)
     # ... and the [:, :n_envs] views callers use
     self.obs_image = self._obs_image[:, :n]      # obs['image'][a]     uint8[A, N, V, V, 3]
     self.obs_dir = self._obs_dir[:, :n]          # obs['direction'][a] uint8[A, N]
     self.reward = self._reward[:, :n]            # rewards[a]          float64[A, N]
     self.env_reward = None if self._env_reward is None else self._env_reward[:, :n]
     self.done = self._done[:n]                   # collective done     uint8[N]
-    self.agent_state = self._agent_state[:, :n]
-    self.shaper_state = self._shaper_state[:, :n]
-    self.step_state = self._step_state[:n]
+    self.env_state = self._env_state[:n]         # int32[N, A+1], packing in include/mgrid.h
     # action staging buffer in the layout the kernel reads
     self.actions = torch.zeros((A, S), dtype=self.act_torch, device=dev)
     gx, gy = C.c_int32(), C.c_int32()
@@ -124,18 +121,34 @@ class BatchedMultiGrid:
     return {'image': self.obs_image, 'direction': self.obs_dir}
 
   @property
+  def agent_state(self):
+    """int32[A, N] agent words: x:6 | y:6 | dir:2 | v8 shaper state (include/mgrid.h)."""
+    return self.env_state[:, :self.n_agents].t().contiguous()
+
+  @property
+  def step_state(self):
+    """int32[N]: step_count | agent done bits << 16."""
+    return self.env_state[:, self.n_agents].contiguous()
+
+  @property
   def agent_pos(self):
     """int32[A, N, 2] (x, y) — env.agent_pos[a] (v8_robust_ppo.py:242)."""
     s = self.agent_state
-    return torch.stack((s & 255, (s >> 8) & 255), dim=-1)
+    return torch.stack((s & 63, (s >> 6) & 63), dim=-1)
 
   @property
   def agent_dir(self):
-    return (self.agent_state >> 16) & 3
+    return (self.agent_state >> 12) & 3
 
   @property
   def step_count(self):
     return self.step_state & 0xFFFF
+
+  def launch_info(self):
+    v = [C.c_int32() for _ in range(4)]
+    _lib.check(self.L.mg_get_launch_info(self.h, *[C.byref(x) for x in v]))
+    return {'path': {1: 'generic', 2: 'table'}[v[0].value], 'block_threads': v[1].value,
+            'grid_blocks': v[2].value, 'lds_bytes': v[3].value}
 
   # ---- reference contract -------------------------------------------------------------------
   def reset(self, mask=None, spawn=None):

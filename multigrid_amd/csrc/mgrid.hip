@@ -1,33 +1,44 @@
 // mgrid.hip — MI355X (gfx950) kernels and C ABI of the batched MultiGrid step path.
 //
-// One lane owns one env; one wavefront owns 64 consecutive envs.  Per launch every env does
+// One lane owns one env; one wavefront owns 64 consecutive envs ("chunk").  Per launch every env does
 //   step_count++ -> agent order -> per-agent action resolution (serial in that order) ->
 //   respawn -> collective done -> v8 reward shaping -> optional auto-reset -> egocentric obs
 // i.e. MultiGridEnv.step (envs/gym_multigrid/multigrid.py:963-995) + gen_obs (:1037-1083) +
 // v8 shape_rewards (v8_robust_ppo.py:171-220), for N envs at once.
 //
-// Memory plan (all arrays agent-major, see include/mgrid.h):
-//   reads : actions A B, agent words 4A B, shaper words 4A B, step word 4 B      (coalesced dwords)
+// Memory plan (see include/mgrid.h for the layouts):
+//   reads : actions A B, env_state 4(A+1) B (one 16-B vector per env for A=3)
 //   writes: obs image A*V*V*3 B (staged in LDS, stored as whole 16-B vectors of a contiguous
-//           64-env chunk), obs dir A B, reward 8A B, done 1 B, state write-back
-//   LDS   : padded static map (one dword per cell), goal-distance LUT, 64*V*V*3 B staging per wave
+//           64-env chunk), obs dir A B, reward 8A B, done 1 B, env_state write-back
+//   LDS   : per-wave 64*V*V*3 B staging; padded static map (one dword per cell); goal-distance
+//           LUT; and, on the table path, the precomputed static view of every (free cell, dir).
+// Workgroups are persistent (grid-stride over chunks) so the LDS tables are filled once per CU.
 // No inter-workgroup communication, no atomics except the (rare) error word.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <algorithm>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "mgrid.h"
 #include "mg_vis.h"
 
+// Ablation switch for timing-only builds (tools/build_variant.sh): 0 = product,
+// 1 = skip the obs global stores (LDS staging kept), 2 = skip obs entirely.
+#ifndef MG_ABL
+#define MG_ABL 0
+#endif
+
 namespace {
 
-constexpr int kBlock = 256;          // 4 wavefronts
 constexpr int kWave = 64;
+constexpr int kMaxBlock = 1024;
 constexpr int kMaxAttempts = 256;    // rejection-sampling cap, then a deterministic scan
+constexpr int kLdsLimit = 160 * 1024;
 enum { P_ORDER = 0, P_RESPAWN = 1, P_SPAWN = 2, P_ACTION = 3 };
 enum { OP_STEP = 0, OP_RESET = 1 };
 
@@ -37,15 +48,31 @@ constexpr uint32_t F_FREE = 1u << 25;    // grid.get(...) is None
 constexpr uint32_t F_KILL = 1u << 26;    // goal or lava: agent_is_done
 constexpr uint32_t F_GOAL = 1u << 27;
 
+// agent word of env_state (include/mgrid.h): x:6 | y:6 | dir:2 | prev_x:6 | prev_y:6 | valid:1 | stationary:3
+constexpr uint32_t AW_POS = 0xFFFu;          // x | y<<6
+constexpr uint32_t AW_POSDIR = 0x3FFFu;
+__host__ __device__ __forceinline__ int aw_x(uint32_t w) { return (int)(w & 63u); }
+__host__ __device__ __forceinline__ int aw_y(uint32_t w) { return (int)((w >> 6) & 63u); }
+__host__ __device__ __forceinline__ int aw_d(uint32_t w) { return (int)((w >> 12) & 3u); }
+
+template <int V> struct ViewGeom {
+  static constexpr int ROWB = V * V * 3;            // bytes of one image
+  static constexpr int NW = (ROWB + 3) / 4;         // dwords of one image (last holds 3 bytes: ROWB % 4 == 3 for odd V)
+  static constexpr int ENTW = (NW + 1 + 3) / 4 * 4; // table entry: NW stream dwords + 1 visibility dword, 16-B multiple
+  static_assert((ROWB & 3) == 3, "odd view sizes only");
+};
+
 struct Params {
   int32_t W, H, max_steps, see_through, competitive, shaping, auto_reset, act_elem;
-  int32_t op, random_actions, PW, PH;
-  int64_t n_envs, stride;
+  int32_t op, random_actions, PW, PH, n_entries, reserved;
+  int64_t n_envs, stride, n_chunks;
   uint64_t gid_base, t;
   uint32_t seed_lo, seed_hi;
   const uint32_t* map_pad;     // [PH][PW]
   const double* dist_lut;      // [H][W] distance to the shaper's goal cell
   const double* reward_lut;    // [max_steps+1]
+  const uint32_t* view_table;  // [n_entries][ENTW] (table path) : static view of (free cell, dir)
+  const uint16_t* cell_index;  // [H][W] -> free-cell index (table path)
   const void* actions;
   const uint8_t* order;
   const uint32_t* respawn;     // int8x4 per (agent, env)
@@ -57,9 +84,7 @@ struct Params {
   double* reward;
   double* env_reward;
   uint8_t* done;
-  uint32_t* agent_state;
-  uint32_t* shaper_state;
-  uint32_t* step_state;
+  uint32_t* env_state;         // [stride][A+1]
   uint32_t* err;
 };
 
@@ -79,84 +104,83 @@ __device__ __forceinline__ U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint
   return U4{c0, c1, c2, c3};
 }
 
-template <int A>
-__device__ __forceinline__ uint32_t sel(const uint32_t (&v)[A], int a) {
-  uint32_t r = v[0];
-#pragma unroll
-  for (int i = 1; i < A; ++i) r = (a == i) ? v[i] : r;
-  return r;
-}
-template <int A>
-__device__ __forceinline__ void put(uint32_t (&v)[A], int a, uint32_t val) {
-#pragma unroll
-  for (int i = 0; i < A; ++i) v[i] = (a == i) ? val : v[i];
+// Per-agent values that are selected with a RUN-TIME agent id live in packed integers and are
+// extracted with shifts: pd = (x:6 | y:6 | dir:2) of every agent, 14 bits each, in one u64;
+// actions 3 bits each in one u32.  (A select chain over array elements gets turned by hipcc into
+// an indexed scratch-memory load, whose s_waitcnt vmcnt would also drain the obs stores in flight.)
+// Arrays below are only ever indexed with compile-time constants.
+__device__ __forceinline__ uint32_t pd_get(uint64_t pd, int a) { return (uint32_t)(pd >> (14 * a)) & AW_POSDIR; }
+__device__ __forceinline__ uint64_t pd_set(uint64_t pd, int a, uint32_t v) {
+  return (pd & ~((uint64_t)AW_POSDIR << (14 * a))) | ((uint64_t)v << (14 * a));
 }
 
 // place_obj's acceptance test (multigrid.py:603-613) on the shared static map.
 // occ = bit mask of agents whose position currently counts (agent_pos not None).
 template <int A>
-__device__ __forceinline__ bool cell_free(const Params& p, const uint32_t* map, const uint32_t (&ag)[A],
+__device__ __forceinline__ bool cell_free(const Params& p, const uint32_t* map, uint64_t pd,
                                           uint32_t occ, int x, int y) {
   if ((unsigned)x >= (unsigned)p.W || (unsigned)y >= (unsigned)p.H) return false;
   const int pad = (p.PW - p.W) >> 1;
   if (!(map[(y + pad) * p.PW + x + pad] & F_FREE)) return false;
-  const uint32_t pos = (uint32_t)x | ((uint32_t)y << 8);
+  const uint32_t pos = (uint32_t)x | ((uint32_t)y << 6);
   bool ok = true;
 #pragma unroll
-  for (int b = 0; b < A; ++b) ok = ok && !(((occ >> b) & 1u) && (ag[b] & 0xFFFFu) == pos);
+  for (int b = 0; b < A; ++b) ok = ok && !(((occ >> b) & 1u) && (pd_get(pd, b) & AW_POS) == pos);
   return ok;
 }
 
-// place_one_agent + place_agent_at_pos (multigrid.py:646-675): returns x | y<<8 | dir<<16.
-// inj != nullptr: the draw the reference accepted is injected (int8x4 = x, y, dir, 0).
+// place_one_agent + place_agent_at_pos (multigrid.py:646-675): returns x | y<<6 | dir<<12, with
+// MG_ERR_* bits (if any) in bits 16+.  inj != nullptr: the draw the reference accepted is
+// injected (int8x4 = x, y, dir, 0).  Rare path (goal touch, reset).
 template <int A>
-__device__ __forceinline__ uint32_t place_agent(const Params& p, const uint32_t* map, const uint32_t (&ag)[A], uint32_t occ,
-                                int a, int purpose, const uint32_t* inj, int64_t n, uint32_t gid, uint32_t& err) {
+__device__ __forceinline__ uint32_t place_agent(const Params& p, const uint32_t* map, uint64_t pd, uint32_t occ,
+                                                int a, int purpose, const uint32_t* inj, int64_t n, uint32_t gid) {
   int x = -1, y = -1, dir = 0;
+  uint32_t err = 0;
   if (inj) {
     const uint32_t w = inj[(int64_t)a * p.stride + n];
     x = (int8_t)(w & 255u); y = (int8_t)((w >> 8) & 255u); dir = (int8_t)((w >> 16) & 255u);
-    if (x < 0) { err |= MG_ERR_MISSING_DRAW; x = -1; }
-    else if (!cell_free<A>(p, map, ag, occ, x, y) || (unsigned)dir > 3u) { err |= MG_ERR_BAD_RESPAWN; x = -1; }
+    if (x < 0) { err = MG_ERR_MISSING_DRAW; x = -1; }
+    else if (!cell_free<A>(p, map, pd, occ, x, y) || (unsigned)dir > 3u) { err = MG_ERR_BAD_RESPAWN; x = -1; }
   } else {
     for (int k = 0; k < kMaxAttempts; ++k) {   // while True: multigrid.py:589-619 (bounded here)
       const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32),
                           ((uint32_t)purpose << 28) | ((uint32_t)a << 20) | (uint32_t)k, p.seed_lo, p.seed_hi);
       const int cx = (int)__umulhi(r.x, (uint32_t)p.W), cy = (int)__umulhi(r.y, (uint32_t)p.H);
-      if (cell_free<A>(p, map, ag, occ, cx, cy)) { x = cx; y = cy; dir = (int)(r.z >> 30); break; }
+      if (cell_free<A>(p, map, pd, occ, cx, cy)) { x = cx; y = cy; dir = (int)(r.z >> 30); break; }
     }
   }
   if (x < 0) {   // exit condition of the sampling loop: first free cell in storage order, dir 0
     dir = 0;
     for (int j = 0; j < p.H && x < 0; ++j)
       for (int i = 0; i < p.W; ++i)
-        if (cell_free<A>(p, map, ag, occ, i, j)) { x = i; y = j; break; }
+        if (cell_free<A>(p, map, pd, occ, i, j)) { x = i; y = j; break; }
     if (x < 0) { x = 0; y = 0; }
   }
-  return (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)dir << 16);
+  return (uint32_t)x | ((uint32_t)y << 6) | ((uint32_t)dir << 12) | (err << 16);
 }
 
-// Egocentric view of agent `a` (gen_obs_grid + encode, multigrid.py:997-1035, 1081) for the 64
-// envs of this wave, staged in LDS and stored to HBM as one contiguous 64*V*V*3-byte chunk.
+// ---------------------------------------------------------------------------------------------
+// Egocentric view (gen_obs_grid + encode, multigrid.py:997-1035, 1081).
 //
 // Closed form of slice + rotate_left x (dir+1): view cell (vx,vy) is world cell
 //   pos + f*(V-1-vy) + r*(vx - V/2),  f = DIR_TO_VEC[dir], r = (-f.y, f.x)
-// (equivalent to get_view_coords, multigrid.py:723-741).  Another agent seen in the view is
-// encoded (10, id, (dir_other - dir_obs - 1) mod 4) (rotate_left's dir-1 per turn, :289-295).
-template <int A, int V>
-__device__ __forceinline__ void write_obs(const Params& p, const uint32_t* map, const uint32_t (&ag)[A], int a,
-                                          uint32_t* stage, int lane, uint8_t* gchunk) {
-  constexpr int ROWB = V * V * 3;           // bytes of one image
-  constexpr int NW = (ROWB + 3) / 4;        // dwords of one image (last one holds 3 bytes: ROWB % 4 == 3 for odd V)
-  static_assert((ROWB & 3) == 3, "odd view sizes only");
+// (equivalent to get_view_coords, multigrid.py:723-741).  Agents are transparent, so the static
+// part of a view (cell codes with visibility applied, own cell = empty) depends only on
+// (pos, dir): `static_view` computes it from the map; on the table path it was computed once on
+// the host for every (free cell, dir) and is simply fetched from LDS.
+// Output: s[0..NW-1] = the V*V 3-byte codes as a dword stream, vm = visibility bits (vx*V+vy).
+// ---------------------------------------------------------------------------------------------
+template <int V>
+__device__ __forceinline__ void static_view(const Params& p, const uint32_t* map, uint32_t me,
+                                            uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t& vm) {
+  constexpr int NW = ViewGeom<V>::NW;
   const int pad = (p.PW - p.W) >> 1;
-  const uint32_t me = ag[a];
-  const int x = (int)(me & 255u), y = (int)((me >> 8) & 255u), d = (int)((me >> 16) & 3u);
+  const int x = aw_x(me), y = aw_y(me), d = aw_d(me);
   const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
   const int rx = -fy, ry = fx;
   const int dr = rx + p.PW * ry, df = fx + p.PW * fy;
   const int i0 = (y + pad + fy * (V - 1) - ry * (V / 2)) * p.PW + (x + pad + fx * (V - 1) - rx * (V / 2));
-
   uint32_t code[V * V];
   uint32_t opq[V], vis[V];
 #pragma unroll
@@ -175,27 +199,53 @@ __device__ __forceinline__ void write_obs(const Params& p, const uint32_t* map, 
   } else {
     mg_vis_rows<V>(opq, vis);
   }
-  // own cell <- carried object or None, after process_vis (multigrid.py:1029-1033)
-  {
-    const uint32_t carry = me >> 24;
-    code[(V / 2) * V + (V - 1)] = carry ? ((carry >> 3) | ((carry & 7u) << 8)) : (uint32_t)MG_T_EMPTY;
-  }
-
-  // pack the V*V 3-byte codes into a dword stream (all positions compile-time)
-  uint32_t s[NW + 1];
+  // own cell <- carried object or None, after process_vis (multigrid.py:1029-1033); nothing can
+  // be carried on a static map
+  code[(V / 2) * V + (V - 1)] = (uint32_t)MG_T_EMPTY;
 #pragma unroll
   for (int i = 0; i <= NW; ++i) s[i] = 0;
+  vm = 0;
 #pragma unroll
   for (int vx = 0; vx < V; ++vx)
 #pragma unroll
     for (int vy = 0; vy < V; ++vy) {
       const int c = vx * V + vy;
-      const uint32_t v = ((vis[vy] >> vx) & 1u) ? code[c] : 0u;   // unseen -> (0,0,0)
+      const uint32_t seen = (vis[vy] >> vx) & 1u;
+      const uint32_t v = seen ? code[c] : 0u;                     // unseen -> (0,0,0)
+      vm |= (uint64_t)seen << c;
       const int b = 3 * c, wi = b >> 2, sh = (b & 3) * 8;
       s[wi] |= v << sh;
       if (sh > 8) s[wi + 1] |= v >> (32 - sh);
     }
+}
 
+template <int V>
+__device__ __forceinline__ void table_view(const Params& p, const uint32_t* table, const uint16_t* cidx, uint32_t me,
+                                           uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t& vm) {
+  constexpr int NW = ViewGeom<V>::NW, ENTW = ViewGeom<V>::ENTW;
+  const int e = (int)cidx[aw_y(me) * p.W + aw_x(me)] * 4 + aw_d(me);
+  const uint4* row = reinterpret_cast<const uint4*>(table + e * ENTW);
+  uint32_t t[ENTW];
+#pragma unroll
+  for (int i = 0; i < ENTW / 4; ++i) {
+    const uint4 q = row[i];
+    t[4 * i] = q.x; t[4 * i + 1] = q.y; t[4 * i + 2] = q.z; t[4 * i + 3] = q.w;
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) s[i] = t[i];
+  s[NW] = 0;
+  vm = t[NW];
+}
+
+// Stage the 64 images of this wave in LDS and stream them to HBM as one contiguous chunk.
+template <int A, int V>
+__device__ __forceinline__ void emit_obs(uint64_t pd, int a, uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t vm,
+                                         uint32_t* stage, int lane, uint8_t* gchunk) {
+  constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
+  const uint32_t me = pd_get(pd, a);
+  const int x = aw_x(me), y = aw_y(me), d = aw_d(me);
+  const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
+  const int rx = -fy, ry = fx;
   // This lane's image occupies bytes [lane*ROWB, lane*ROWB+ROWB) of the wave chunk, which is not
   // dword aligned.  A lane owns the chunk dwords that START inside its byte range; the last of
   // them is completed with the first bytes of the next lane's stream.
@@ -211,24 +261,23 @@ __device__ __forceinline__ void write_obs(const Params& p, const uint32_t* map, 
     const uint32_t v = __builtin_amdgcn_alignbyte(s[j + 1], s[j], h);
     if (j < NW - 1 || j < cnt) stage[d0 + j] = v;
   }
-  // other agents: patch their cell (3 bytes) if it lies in the view and is visible
+  // other agents: patch their cell (3 bytes) if it lies in the view and is visible; encoded
+  // (10, id, (dir_other - dir_obs - 1) mod 4)  (Agent.encode :137-139, rotate_left :289-295)
   uint8_t* sb = reinterpret_cast<uint8_t*>(stage) + b0;
 #pragma unroll
   for (int b = 0; b < A; ++b) {
     if (b == a) continue;
-    const uint32_t o = ag[b];
-    const int ox = (int)(o & 255u) - x, oy = (int)((o >> 8) & 255u) - y;
+    const uint32_t o = pd_get(pd, b);
+    const int ox = aw_x(o) - x, oy = aw_y(o) - y;
     const int along = ox * fx + oy * fy, side = ox * rx + oy * ry;
     const int vy = V - 1 - along, vx = side + V / 2;
     if ((unsigned)vx < (unsigned)V && (unsigned)vy < (unsigned)V) {
-      uint32_t vrow = vis[0];
-#pragma unroll
-      for (int j = 1; j < V; ++j) vrow = (vy == j) ? vis[j] : vrow;
-      if ((vrow >> vx) & 1u) {
-        uint8_t* q = sb + (vx * V + vy) * 3;
+      const int c = vx * V + vy;
+      if ((vm >> c) & 1u) {
+        uint8_t* q = sb + c * 3;
         q[0] = (uint8_t)MG_T_AGENT;
         q[1] = (uint8_t)b;
-        q[2] = (uint8_t)((((o >> 16) & 3u) - (uint32_t)d - 1u) & 3u);
+        q[2] = (uint8_t)(((uint32_t)aw_d(o) - (uint32_t)d - 1u) & 3u);
       }
     }
   }
@@ -243,68 +292,122 @@ __device__ __forceinline__ void write_obs(const Params& p, const uint32_t* map, 
 #pragma unroll
   for (int i = 0; i < (NV + kWave - 1) / kWave; ++i) {
     const int idx = i * kWave + lane;
+#if MG_ABL == 1
+    if (idx < NV) { uint4 v = src[idx]; asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+#else
     if (idx < NV) dst[idx] = src[idx];
+#endif
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int A, int V>
-__global__ __launch_bounds__(kBlock) void mg_kernel(const Params p) {
-  constexpr int ROWB = V * V * 3;
-  extern __shared__ __align__(16) uint8_t smem[];
-  // LDS carve: [stage: 4 waves x 64*ROWB B][dist LUT: W*H f64][map: PW*PH u32]
-  uint32_t* stage_all = reinterpret_cast<uint32_t*>(smem);
-  double* dist = reinterpret_cast<double*>(smem + (kBlock / kWave) * kWave * ROWB);
-  uint32_t* map = reinterpret_cast<uint32_t*>(dist + p.W * p.H);
+// Inputs of one chunk, fetched one iteration ahead of their use (software prefetch: vmcnt
+// retires in issue order, so loads issued BEFORE the previous chunk's stores do not wait for them).
+// Inputs of one chunk, requested one iteration ahead of their use.  The loads are inline asm so
+// that hipcc neither waits for them at once nor drains the obs stores in flight when the values
+// are finally used: vmcnt retires vector-memory operations in issue order, so a counted
+// s_waitcnt vmcnt(K) issued after >= K younger stores retires these loads without waiting for
+// those stores (wait_chunk).  Nothing is computed from the registers before that wait.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct ChunkIn {
+  u32x4 q;          // A == 3: the four env_state words
+  uint32_t w[5];    // other A: env_state words, compile-time indices only
+  uint32_t act[4];  // raw actions (low 32 bits for 64-bit actions)
+};
 
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
-  for (int i = tid; i < p.PW * p.PH; i += kBlock) map[i] = p.map_pad[i];
-  for (int i = tid; i < p.W * p.H; i += kBlock) dist[i] = p.dist_lut[i];
-  __syncthreads();
+__device__ __forceinline__ uint32_t asm_load_u32(const void* ptr) {
+  uint32_t v;
+  asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(ptr) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint32_t asm_load_u8(const void* ptr) {
+  uint32_t v;
+  asm volatile("global_load_ubyte %0, %1, off" : "=&v"(v) : "v"(ptr) : "memory");
+  return v;
+}
 
-  const int64_t env0 = ((int64_t)blockIdx.x * (kBlock / kWave) + wv) * kWave;
-  if (env0 >= p.stride) return;                 // whole wave beyond the allocation (wave-uniform)
+template <int A>
+__device__ __forceinline__ void load_chunk(const Params& p, int64_t env0, int lane, ChunkIn& in) {
+  const int64_t n = env0 + lane;
+  in.q = u32x4{0, 0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < 5; ++a) in.w[a] = 0u;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) in.act[a] = 6u;
+  if (A == 3) {
+    const void* ptr = reinterpret_cast<const uint4*>(p.env_state) + n;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(in.q) : "v"(ptr) : "memory");
+  } else {
+#pragma unroll
+    for (int a = 0; a <= A; ++a) in.w[a] = asm_load_u32(p.env_state + n * (A + 1) + a);
+  }
+  if (p.op == OP_STEP && !p.random_actions) {
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      const int64_t i = (int64_t)a * p.stride + n;
+      if (p.act_elem == MG_ACT_U8) in.act[a] = asm_load_u8(static_cast<const uint8_t*>(p.actions) + i);
+      else if (p.act_elem == MG_ACT_I32) in.act[a] = asm_load_u32(static_cast<const uint32_t*>(p.actions) + i);
+      else in.act[a] = asm_load_u32(static_cast<const uint32_t*>(p.actions) + 2 * i);   // little-endian low half
+    }
+  }
+}
+
+// Retire the loads of load_chunk: at most K vector-memory operations younger than them may stay
+// in flight.  The registers are operands so that no use (not even a copy) can be moved above it.
+template <int K>
+__device__ __forceinline__ void wait_chunk(ChunkIn& in) {
+  asm volatile("s_waitcnt vmcnt(%9)"
+               : "+v"(in.q), "+v"(in.w[0]), "+v"(in.w[1]), "+v"(in.w[2]), "+v"(in.w[3]), "+v"(in.w[4]),
+                 "+v"(in.act[0]), "+v"(in.act[1]), "+v"(in.act[2])
+               : "n"(K)
+               : "memory");
+  asm volatile("" : "+v"(in.act[3]));
+}
+
+// One chunk (64 envs) of one step()/reset().
+template <int A, int V, bool TAB>
+__device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, const double* dist, const uint32_t* table,
+                                         const uint16_t* cidx, uint32_t* stage, int lane, int64_t env0,
+                                         const ChunkIn& in, uint32_t& err_acc) {
+  constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
   const int64_t n = env0 + lane;
   const bool active = n < p.n_envs;
   const uint32_t gid = (uint32_t)(p.gid_base + (uint64_t)n);
-  uint32_t* stage = stage_all + wv * (kWave * ROWB / 4);
+  const int pad = (p.PW - p.W) >> 1;
 
-  uint32_t ag[A], sh[A], acts[A], st, err = 0;
-  double rew[A];
+  uint64_t pd = 0;              // x | y<<6 | dir<<12 of every agent, 14 bits each
+  uint32_t shw[A];              // v8 shaper bits of each agent word (bits 14..29)
+  uint32_t win[5];
+  if (A == 3) { win[0] = in.q.x; win[1] = in.q.y; win[2] = in.q.z; win[3] = in.q.w; win[4] = 0u; }
+  else {
+#pragma unroll
+    for (int a = 0; a < 5; ++a) win[a] = in.w[a];
+  }
+  uint32_t actw = 0, st = win[A], err = 0;
 #pragma unroll
   for (int a = 0; a < A; ++a) {
-    ag[a] = p.agent_state[(int64_t)a * p.stride + n];
-    sh[a] = p.shaper_state[(int64_t)a * p.stride + n];
-    // keep every later LDS index in range whatever the buffers hold
-    const uint32_t cx = min(ag[a] & 255u, (uint32_t)(p.W - 1)), cy = min((ag[a] >> 8) & 255u, (uint32_t)(p.H - 1));
-    ag[a] = (ag[a] & 0xFF030000u) | cx | (cy << 8);
-    rew[a] = 0.0;
-    acts[a] = 6;
+    actw |= min(in.act[a], 7u) << (3 * a);
+    // keep every later LDS index in range whatever the buffer holds
+    const uint32_t w = win[a];
+    const uint32_t cx = min(w & 63u, (uint32_t)(p.W - 1)), cy = min((w >> 6) & 63u, (uint32_t)(p.H - 1));
+    pd |= (uint64_t)(cx | (cy << 6) | (w & 0x3000u)) << (14 * a);
+    shw[a] = w & ~AW_POSDIR;
   }
-  st = p.step_state[n];
   uint32_t done_flag = 0;
-  const int pad = (p.PW - p.W) >> 1;
 
   if (p.op == OP_STEP) {
     // ---- actions -------------------------------------------------------------------------
     if (p.random_actions) {
       const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), (uint32_t)P_ACTION << 28, p.seed_lo, p.seed_hi);
       const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+      actw = 0;
 #pragma unroll
-      for (int a = 0; a < A; ++a) acts[a] = __umulhi(rr[a & 3], 7u);
+      for (int a = 0; a < A; ++a) actw |= __umulhi(rr[a & 3], 7u) << (3 * a);
       if (p.actions_out && active) {
 #pragma unroll
-        for (int a = 0; a < A; ++a) p.actions_out[(int64_t)a * p.stride + n] = (uint8_t)acts[a];
-      }
-    } else {
-#pragma unroll
-      for (int a = 0; a < A; ++a) {
-        const int64_t i = (int64_t)a * p.stride + n;
-        if (p.act_elem == MG_ACT_U8) acts[a] = static_cast<const uint8_t*>(p.actions)[i];
-        else if (p.act_elem == MG_ACT_I32) acts[a] = (uint32_t)static_cast<const int32_t*>(p.actions)[i];
-        else acts[a] = (uint32_t)static_cast<const int64_t*>(p.actions)[i];
+        for (int a = 0; a < A; ++a) p.actions_out[(int64_t)a * p.stride + n] = (uint8_t)((actw >> (3 * a)) & 7u);
       }
     }
     // ---- step_count += 1 (multigrid.py:968) ----------------------------------------------
@@ -312,135 +415,109 @@ __global__ __launch_bounds__(kBlock) void mg_kernel(const Params p) {
     uint32_t dbits = st >> 16;
     if (step > 0xFFFFu) step = 0xFFFFu;
 
-    // ---- agent order (multigrid.py:973-974) ----------------------------------------------
-    int ord[A];
+    // ---- agent order (multigrid.py:973-974), packed 2 bits per slot --------------------------
+    uint32_t ordw = 0;
 #pragma unroll
-    for (int k = 0; k < A; ++k) ord[k] = k;
+    for (int k = 0; k < A; ++k) ordw |= (uint32_t)k << (2 * k);
     if (p.order) {
-      uint32_t seen = 0;
+      uint32_t seen = 0, w = 0;
 #pragma unroll
       for (int k = 0; k < A; ++k) {
-        ord[k] = p.order[(int64_t)k * p.stride + n];
-        if (ord[k] < A) seen |= 1u << ord[k];
+        const uint32_t o = p.order[(int64_t)k * p.stride + n];
+        if (o < (uint32_t)A) seen |= 1u << o;
+        w |= (o & 3u) << (2 * k);
       }
-      if (seen != (1u << A) - 1u) {
-        if (active) err |= MG_ERR_BAD_ORDER;
-#pragma unroll
-        for (int k = 0; k < A; ++k) ord[k] = k;
-      }
+      if (seen != (1u << A) - 1u) { if (active) err |= MG_ERR_BAD_ORDER; }
+      else ordw = w;
     } else if (A > 1) {
       const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), (uint32_t)P_ORDER << 28, p.seed_lo, p.seed_hi);
       const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
-      // Fisher-Yates from the top, as np.random.shuffle does; static swaps via selects
+      // Fisher-Yates from the top, as np.random.shuffle does: swap slots i and j = rand(i+1)
 #pragma unroll
       for (int i = A - 1, w = 0; i >= 1; --i, ++w) {
-        const int j = (int)__umulhi(rr[w & 3], (uint32_t)(i + 1));
-        const int oi = ord[i];
-        int oj = ord[0];
-#pragma unroll
-        for (int q = 1; q < A; ++q) oj = (j == q) ? ord[q] : oj;
-#pragma unroll
-        for (int q = 0; q < A; ++q) ord[q] = (j == q) ? oi : ord[q];
-        ord[i] = oj;
+        const uint32_t j = __umulhi(rr[w & 3], (uint32_t)(i + 1));
+        const uint32_t oi = (ordw >> (2 * i)) & 3u, oj = (ordw >> (2 * j)) & 3u;
+        ordw = (ordw & ~(3u << (2 * i)) & ~(3u << (2 * j))) | (oi << (2 * j));
+        ordw = (ordw & ~(3u << (2 * i))) | (oj << (2 * i));
       }
     }
 
-    // ---- step_one_agent in that order (multigrid.py:860-924) ------------------------------
-#pragma unroll
+    // ---- step_one_agent in that order (multigrid.py:860-924), branch-free except respawn -----
+    uint32_t gbits = 0;          // agents whose forward touched the goal this step
+#pragma unroll 1
     for (int k = 0; k < A; ++k) {
-      const int a = ord[k];
-      uint32_t s = sel<A>(ag, a);
-      const uint32_t act = sel<A>(acts, a);
-      int x = (int)(s & 255u), y = (int)((s >> 8) & 255u), d = (int)((s >> 16) & 3u);
-      const uint32_t hi = s & 0xFF000000u;
+      const int a = (int)((ordw >> (2 * k)) & 3u);
+      const uint32_t s = pd_get(pd, a);
+      const uint32_t act = (actw >> (3 * a)) & 7u;
+      const int x = aw_x(s), y = aw_y(s), d = aw_d(s);
       const int fx = x + (d == 0) - (d == 2), fy = y + (d == 1) - (d == 3);   // front_pos, pre-action
-      double r = 0.0;
-      if (act == 0u) {
-        d = (d + 3) & 3;
-      } else if (act == 1u) {
-        d = (d + 1) & 3;
-      } else if (act == 2u) {
-        const uint32_t fpos = (uint32_t)fx | ((uint32_t)fy << 8);
-        bool blocked = false;
+      const uint32_t fpos = (uint32_t)fx | ((uint32_t)fy << 6);
+      bool blocked = false;                                                   // _forward :910-913
 #pragma unroll
-        for (int b = 0; b < A; ++b) blocked = blocked || (b != a && (ag[b] & 0xFFFFu) == fpos);
-        if (!blocked) {
-          const uint32_t cell = map[(fy + pad) * p.PW + fx + pad];
-          if (cell & F_KILL) {                       // goal or lava: agent_is_done (:815-832)
-            dbits |= 1u << a;
-            if (cell & F_GOAL)                       // _reward(), re-read cell is still the goal (:881-883)
-              r = (step <= (uint32_t)p.max_steps) ? p.reward_lut[step]
-                                                  : 1.0 - 0.9 * ((double)step / (double)p.max_steps);
-            const uint32_t np_ = place_agent<A>(p, map, ag, ((1u << A) - 1u) & ~(1u << a), a, P_RESPAWN,
-                                                p.respawn, n, gid, err);
-            x = (int)(np_ & 255u); y = (int)((np_ >> 8) & 255u); d = (int)((np_ >> 16) & 3u);
-          } else if (cell & F_FREE) {                // move_agent (:834-847)
-            x = fx; y = fy;
-          }                                           // wall: nothing moves, still "successful"
-        }
-      } else if (act > 6u) {
-        err |= MG_ERR_BAD_ACTION;                     // assert False (:902)
-      }                                               // pickup/drop/toggle/done: no-ops on a static map
-      s = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)d << 16) | hi;
-      put<A>(ag, a, s);
-#pragma unroll
-      for (int i = 0; i < A; ++i) rew[i] = (a == i) ? r : rew[i];
+      for (int b = 0; b < A; ++b) blocked = blocked || (b != a && (pd_get(pd, b) & AW_POS) == fpos);
+      const uint32_t cell = map[(fy + pad) * p.PW + fx + pad];
+      const bool go = (act == 2u) && !blocked;
+      const int nd = (act == 0u) ? ((d + 3) & 3) : (act == 1u) ? ((d + 1) & 3) : d;   // :867-876
+      uint32_t npd = (s & AW_POS) | ((uint32_t)nd << 12);
+      if (go && (cell & F_FREE)) npd = fpos | ((uint32_t)d << 12);            // move_agent :834-847
+      // (a wall ahead: nothing moves, still "successful"; pickup/drop/toggle/done: no-ops here)
+      if (go && (cell & F_KILL)) {                                            // goal or lava: agent_is_done :815-832
+        dbits |= 1u << a;
+        if (cell & F_GOAL) gbits |= 1u << a;                                  // cell re-read is still the goal :881-883
+        const uint32_t w = place_agent<A>(p, map, pd, ((1u << A) - 1u) & ~(1u << a), a, P_RESPAWN, p.respawn, n, gid);
+        npd = w & AW_POSDIR;
+        err |= w >> 16;
+      }
+      if (act > 6u) err |= MG_ERR_BAD_ACTION;                                 // assert False :902
+      pd = pd_set(pd, a, npd);
     }
+    // _reward() (multigrid.py:883): the same value for every agent that touched the goal this step
+    double rgoal = 0.0;
+    if (gbits) rgoal = (step <= (uint32_t)p.max_steps) ? p.reward_lut[step] : 1.0 - 0.9 * ((double)step / (double)p.max_steps);
 
     // ---- collective done (multigrid.py:986-993) -------------------------------------------
     done_flag = (p.competitive && dbits != 0u) || (step >= (uint32_t)p.max_steps);
 
     // ---- v8 shape_rewards (v8_robust_ppo.py:171-220), float64, one rounding per operation ---
-    double out_rew[A];
+    double rew[A], out_rew[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {
+      rew[a] = ((gbits >> a) & 1u) ? rgoal : 0.0;
       out_rew[a] = rew[a];
       if (p.shaping == MG_SHAPING_V8) {
-        const int x = (int)(ag[a] & 255u), y = (int)((ag[a] >> 8) & 255u);
-        uint32_t w = sh[a];
-        if (rew[a] > 0.0) {                           // v8:181-186
+        const uint32_t w = shw[a], me = pd_get(pd, a), act = (actw >> (3 * a)) & 7u;
+        const int x = aw_x(me), y = aw_y(me);
+        uint32_t nw = 0;                              // goal touch: prev_* cleared, count 0 (v8:181-186)
+        if (rew[a] > 0.0) {
           out_rew[a] = 5.0;
-          w = 0u;
         } else {
           double r = 0.0;
-          const bool has = (w >> 16) & 1u;
-          const int px = (int)(w & 255u), py = (int)((w >> 8) & 255u);
-          uint32_t stat = w >> 17;
+          const bool has = (w >> 26) & 1u;
+          const int px = (int)((w >> 14) & 63u), py = (int)((w >> 20) & 63u);
+          uint32_t stat = (w >> 27) & 7u;
           const double cur = dist[y * p.W + x];       // np.linalg.norm(pos - goal), v8:192
           if (has) {
             const double prev = dist[min(py, p.H - 1) * p.W + min(px, p.W - 1)];
             r = r + (prev - cur) * 0.2;               // v8:193-195
             if (px == x && py == y) {                 // v8:199-206
-              stat += 1u;
+              stat = min(stat + 1u, 7u);              // only "> 3" is ever tested: saturating is exact
               if (stat > 3u) r = r - 0.05;
             } else {
               stat = 0u;
               r = r + 0.02;
             }
           }
-          if (acts[a] == 2u) r = r + 0.02;            // v8:209-212
-          else if (acts[a] <= 1u) r = r + 0.01;
+          if (act == 2u) r = r + 0.02;                // v8:209-212
+          else if (act <= 1u) r = r + 0.01;
           if (-0.2 > r) r = -0.2;                     // max(reward, -0.2), v8:215
           out_rew[a] = r;
-          if (stat > 0x7FFFu) stat = 0x7FFFu;
-          w = (uint32_t)x | ((uint32_t)y << 8) | (1u << 16) | (stat << 17);   // v8:218
+          nw = ((uint32_t)x << 14) | ((uint32_t)y << 20) | (1u << 26) | (stat << 27);   // v8:218
         }
-        sh[a] = w;
+        shw[a] = nw;
       }
     }
 
-    // ---- auto-reset: reset() of the finished env inside the same launch --------------------
     st = step | (dbits << 16);
-    if (done_flag && p.auto_reset) {
-#pragma unroll
-      for (int a = 0; a < A; ++a) {
-        const uint32_t np_ = place_agent<A>(p, map, ag, (1u << a) - 1u, a, P_SPAWN, p.reset_spawn, n, gid, err);
-        ag[a] = np_;                                  // carrying cleared (multigrid.py:490)
-        sh[a] = 0u;                                   // v8:227-229
-      }
-      st = 0u;
-    }
-
     if (active) {
 #pragma unroll
       for (int a = 0; a < A; ++a) {
@@ -450,36 +527,105 @@ __global__ __launch_bounds__(kBlock) void mg_kernel(const Params p) {
       }
       p.done[n] = (uint8_t)done_flag;
     }
-  } else {
-    // ---- reset() (multigrid.py:466-501; cluttered.py:55-63) --------------------------------
-    const bool m = p.mask ? (p.mask[active ? n : 0] != 0) : true;
-    if (m) {
-#pragma unroll
-      for (int a = 0; a < A; ++a) {
-        const uint32_t np_ = place_agent<A>(p, map, ag, (1u << a) - 1u, a, P_SPAWN, p.reset_spawn, n, gid, err);
-        ag[a] = np_;
-        sh[a] = 0u;
-      }
-      st = 0u;
+  }
+
+  // ---- reset() (multigrid.py:466-501; cluttered.py:55-63): the explicit call, or the auto-reset
+  //      of an env whose step just returned done (same launch) --------------------------------
+  const bool do_reset = (p.op == OP_RESET) ? (p.mask ? (p.mask[active ? n : 0] != 0) : true)
+                                           : (done_flag && p.auto_reset);
+  if (do_reset) {
+#pragma unroll 1
+    for (int a = 0; a < A; ++a) {
+      const uint32_t w = place_agent<A>(p, map, pd, (1u << a) - 1u, a, P_SPAWN, p.reset_spawn, n, gid);
+      pd = pd_set(pd, a, w & AW_POSDIR);
+      err |= w >> 16;
     }
+#pragma unroll
+    for (int a = 0; a < A; ++a) shw[a] = 0u;          // shaper state cleared (v8:227-229)
+    st = 0u;
   }
 
   if (active) {
+    uint32_t wout[A];
 #pragma unroll
-    for (int a = 0; a < A; ++a) {
-      const int64_t i = (int64_t)a * p.stride + n;
-      p.agent_state[i] = ag[a];
-      p.shaper_state[i] = sh[a];
-      p.obs_dir[i] = (uint8_t)((ag[a] >> 16) & 3u);   // obs['direction'][a] (multigrid.py:1083)
+    for (int a = 0; a < A; ++a) wout[a] = shw[a] | pd_get(pd, a);
+    if (A == 3) {
+      reinterpret_cast<uint4*>(p.env_state)[n] = make_uint4(wout[0], wout[A > 1 ? 1 : 0], wout[A > 2 ? 2 : 0], st);
+    } else {
+#pragma unroll
+      for (int a = 0; a < A; ++a) p.env_state[n * (A + 1) + a] = wout[a];
+      p.env_state[n * (A + 1) + A] = st;
     }
-    p.step_state[n] = st;
-    if (err) atomicOr(p.err, err);
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+      p.obs_dir[(int64_t)a * p.stride + n] = (uint8_t)aw_d(pd_get(pd, a));   // obs['direction'][a] (multigrid.py:1083)
+    err_acc |= err;
   }
 
   // ---- gen_obs (multigrid.py:1037-1067) -----------------------------------------------------
+#if MG_ABL != 2
 #pragma unroll
-  for (int a = 0; a < A; ++a)
-    write_obs<A, V>(p, map, ag, a, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB);
+  for (int a = 0; a < A; ++a) {
+    uint32_t s[NW + 1];
+    uint64_t vm;
+    if (TAB) table_view<V>(p, table, cidx, pd_get(pd, a), s, vm);
+    else static_view<V>(p, map, pd_get(pd, a), s, vm);
+    emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB);
+  }
+#endif
+}
+
+template <int A, int V, bool TAB>
+__global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
+  constexpr int ROWB = ViewGeom<V>::ROWB, ENTW = ViewGeom<V>::ENTW;
+  extern __shared__ __align__(16) uint8_t smem[];
+  // LDS carve: [stage: nw x 64*ROWB B][view table (TAB)][dist LUT: W*H f64][map: PW*PH u32][cell index (TAB)]
+  const int nw = blockDim.x >> 6;
+  uint32_t* stage_all = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* table = reinterpret_cast<uint32_t*>(smem + (size_t)nw * kWave * ROWB);
+  double* dist = reinterpret_cast<double*>(table + (TAB ? p.n_entries * ENTW : 0));
+  uint32_t* map = reinterpret_cast<uint32_t*>(dist + p.W * p.H);
+  uint16_t* cidx = reinterpret_cast<uint16_t*>(map + p.PW * p.PH);
+
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
+  if (TAB) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.view_table);
+    uint4* dst = reinterpret_cast<uint4*>(table);
+    for (int i = tid; i < p.n_entries * ENTW / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = tid; i < p.W * p.H; i += blockDim.x) cidx[i] = p.cell_index[i];
+  }
+  for (int i = tid; i < p.PW * p.PH; i += blockDim.x) map[i] = p.map_pad[i];
+  for (int i = tid; i < p.W * p.H; i += blockDim.x) dist[i] = p.dist_lut[i];
+  __syncthreads();
+
+  uint32_t* stage = stage_all + wv * (kWave * ROWB / 4);
+  uint32_t err = 0;
+  // persistent: each wave strides over the chunks on its own (no further workgroup barrier);
+  // the next chunk's inputs are requested before this chunk's stores are issued
+  const int64_t cstride = (int64_t)gridDim.x * nw;
+  int64_t c = (int64_t)blockIdx.x * nw + wv;
+  // vector-memory operations every iteration issues AFTER its prefetch (lower bound: the obs stores)
+#if MG_ABL == 0
+  constexpr int kYounger = (A * ((4 * ROWB + kWave - 1) / kWave)) < 63 ? (A * ((4 * ROWB + kWave - 1) / kWave)) : 63;
+#else
+  constexpr int kYounger = 0;
+#endif
+  ChunkIn cur, nxt;
+  if (c < p.n_chunks) {
+    load_chunk<A>(p, c * kWave, lane, cur);
+    wait_chunk<0>(cur);
+  }
+  for (; c < p.n_chunks; c += cstride) {
+    const int64_t cn = c + cstride;
+    const bool more = cn < p.n_chunks;          // wave-uniform
+    if (more) load_chunk<A>(p, cn * kWave, lane, nxt);
+    do_chunk<A, V, TAB>(p, map, dist, table, cidx, stage, lane, c * kWave, cur, err);
+    if (more) {
+      wait_chunk<kYounger>(nxt);
+      cur = nxt;
+    }
+  }
+  if (err) atomicOr(p.err, err);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -498,11 +644,67 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 typedef void (*kernel_fn)(const Params);
 
-struct Variant { int A, V; kernel_fn fn; };
+struct Variant { int A, V; kernel_fn generic, table; int entw; };
 const Variant kVariants[] = {
-    {1, 5, mg_kernel<1, 5>}, {2, 5, mg_kernel<2, 5>}, {3, 5, mg_kernel<3, 5>}, {4, 5, mg_kernel<4, 5>},
-    {1, 7, mg_kernel<1, 7>}, {2, 7, mg_kernel<2, 7>}, {3, 7, mg_kernel<3, 7>}, {3, 3, mg_kernel<3, 3>},
+    {1, 5, mg_kernel<1, 5, false>, mg_kernel<1, 5, true>, ViewGeom<5>::ENTW},
+    {2, 5, mg_kernel<2, 5, false>, mg_kernel<2, 5, true>, ViewGeom<5>::ENTW},
+    {3, 5, mg_kernel<3, 5, false>, mg_kernel<3, 5, true>, ViewGeom<5>::ENTW},
+    {4, 5, mg_kernel<4, 5, false>, mg_kernel<4, 5, true>, ViewGeom<5>::ENTW},
+    {3, 3, mg_kernel<3, 3, false>, mg_kernel<3, 3, true>, ViewGeom<3>::ENTW},
+    {1, 7, mg_kernel<1, 7, false>, nullptr, 0},
+    {2, 7, mg_kernel<2, 7, false>, nullptr, 0},
+    {3, 7, mg_kernel<3, 7, false>, nullptr, 0},
 };
+
+// Host twin of static_view<V>: the static view of (x, y, dir) as a table entry
+// (NW stream dwords of 3-byte codes with visibility applied, then the visibility bit mask).
+template <int V>
+void host_view_entry(const std::vector<uint32_t>& map, int PW, int pad, bool see_through, int x, int y, int d,
+                     uint32_t* out) {
+  constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW, ENTW = ViewGeom<V>::ENTW;
+  const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3), rx = -fy, ry = fx;
+  uint32_t code[V * V], opq[V], vis[V];
+  for (int j = 0; j < V; ++j) opq[j] = 0;
+  for (int vx = 0; vx < V; ++vx)
+    for (int vy = 0; vy < V; ++vy) {
+      const int wx = x + fx * (V - 1 - vy) + rx * (vx - V / 2), wy = y + fy * (V - 1 - vy) + ry * (vx - V / 2);
+      const uint32_t w = map[(size_t)(wy + pad) * PW + (wx + pad)];
+      code[vx * V + vy] = w & 0xFFFFFFu;
+      opq[vy] |= ((w >> 24) & 1u) << vx;
+    }
+  if (see_through) for (int j = 0; j < V; ++j) vis[j] = (1u << V) - 1u;
+  else mg_vis_rows<V>(opq, vis);
+  code[(V / 2) * V + (V - 1)] = (uint32_t)MG_T_EMPTY;
+  uint8_t bytes[ENTW * 4];
+  memset(bytes, 0, sizeof(bytes));
+  uint32_t vm = 0;
+  for (int vx = 0; vx < V; ++vx)
+    for (int vy = 0; vy < V; ++vy) {
+      const int c = vx * V + vy;
+      const uint32_t seen = (vis[vy] >> vx) & 1u, v = seen ? code[c] : 0u;
+      vm |= seen << c;
+      bytes[3 * c] = (uint8_t)v; bytes[3 * c + 1] = (uint8_t)(v >> 8); bytes[3 * c + 2] = (uint8_t)(v >> 16);
+    }
+  static_assert(ROWB <= NW * 4, "");
+  memcpy(out, bytes, ENTW * 4);
+  out[NW] = vm;
+}
+
+template <int V>
+void vis_hook(const uint64_t* patterns, int64_t n, uint64_t* out) {
+  for (int64_t k = 0; k < n; ++k) {
+    const uint64_t pat = patterns[k];
+    uint64_t res = 0;
+    uint32_t opq[V], vis[V];
+    for (int j = 0; j < V; ++j) opq[j] = 0;
+    for (int i = 0; i < V; ++i)
+      for (int j = 0; j < V; ++j) opq[j] |= (uint32_t)((pat >> (i * V + j)) & 1u) << i;
+    mg_vis_rows<V>(opq, vis);
+    for (int i = 0; i < V; ++i)
+      for (int j = 0; j < V; ++j) res |= (uint64_t)((vis[j] >> i) & 1u) << (i * V + j);
+    out[k] = res;
+  }
+}
 
 }  // namespace
 
@@ -511,10 +713,11 @@ struct mg_handle {
   int device;
   hipStream_t stream;
   bool own_stream;
-  kernel_fn fn;
-  int64_t stride;
-  int PW, PH;
-  size_t lds_bytes;
+  const Variant* var;
+  bool use_table;
+  int n_entries;
+  int64_t stride, n_chunks;
+  int PW, PH, n_cu;
   bool have_map, have_reset;
   uint64_t t;
   int gx, gy;
@@ -522,6 +725,8 @@ struct mg_handle {
   uint32_t* map_pad;
   double* dist_lut;
   double* reward_lut;
+  uint32_t* view_table;
+  uint16_t* cell_index;
   uint32_t* err;
   mg_buffers buf;
   std::vector<void*> allocs;
@@ -550,6 +755,30 @@ int dalloc(mg_handle* h, T** out, size_t count) {
   return MG_OK;
 }
 
+size_t lds_fixed_bytes(const mg_handle* h, bool table) {
+  const mg_config& c = h->cfg;
+  size_t b = (size_t)c.width * c.height * 8 + (size_t)h->PW * h->PH * 4;
+  if (table) b += (size_t)h->n_entries * h->var->entw * 4 + (size_t)c.width * c.height * 2;
+  return (b + 15) / 16 * 16;
+}
+
+// Launch geometry: workgroups are persistent and stride over the 64-env chunks.  Waves per
+// workgroup are chosen so that (a) the LDS tables + per-wave staging fit 160 KB and (b) a small
+// batch still spreads over all CUs.
+void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid_out, size_t* lds_out) {
+  const int rowb = h->cfg.view_size * h->cfg.view_size * 3;
+  const size_t fixed = lds_fixed_bytes(h, table), per_wave = (size_t)kWave * rowb;
+  int nw = table ? 16 : 4;
+  while (nw > 1 && (fixed + nw * per_wave > (size_t)kLdsLimit || h->n_chunks < (int64_t)h->n_cu * nw)) nw >>= 1;
+  const size_t lds = fixed + nw * per_wave;
+  int per_cu = (int)((size_t)kLdsLimit / lds);
+  per_cu = std::max(1, std::min(per_cu, 32 / nw));
+  const int64_t blocks = (h->n_chunks + nw - 1) / nw;
+  *nw_out = nw;
+  *grid_out = (unsigned)std::min<int64_t>(blocks, (int64_t)h->n_cu * per_cu);
+  *lds_out = lds;
+}
+
 int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, const int8_t* respawn,
            const int8_t* reset_spawn, const uint8_t* mask, int random_actions, uint8_t* actions_out) {
   Params p;
@@ -558,39 +787,25 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   p.W = c.width; p.H = c.height; p.max_steps = c.max_steps; p.see_through = c.see_through_walls;
   p.competitive = (c.n_agents == 1) ? 1 : c.competitive;   // multigrid.py:380-381
   p.shaping = c.shaping_kind; p.auto_reset = c.auto_reset; p.act_elem = c.action_dtype;
-  p.op = op; p.random_actions = random_actions; p.PW = h->PW; p.PH = h->PH;
-  p.n_envs = c.n_envs; p.stride = h->stride; p.gid_base = (uint64_t)c.env_id_base; p.t = h->t;
+  p.op = op; p.random_actions = random_actions; p.PW = h->PW; p.PH = h->PH; p.n_entries = h->n_entries;
+  p.n_envs = c.n_envs; p.stride = h->stride; p.n_chunks = h->n_chunks;
+  p.gid_base = (uint64_t)c.env_id_base; p.t = h->t;
   p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32);
   p.map_pad = h->map_pad; p.dist_lut = h->dist_lut; p.reward_lut = h->reward_lut;
+  p.view_table = h->view_table; p.cell_index = h->cell_index;
   p.actions = actions; p.order = order;
   p.respawn = reinterpret_cast<const uint32_t*>(respawn);
   p.reset_spawn = reinterpret_cast<const uint32_t*>(reset_spawn);
   p.mask = mask; p.actions_out = actions_out;
   p.obs_image = h->buf.obs_image; p.obs_dir = h->buf.obs_dir; p.reward = h->buf.reward;
-  p.env_reward = h->buf.env_reward; p.done = h->buf.done; p.agent_state = h->buf.agent_state;
-  p.shaper_state = h->buf.shaper_state; p.step_state = h->buf.step_state; p.err = h->err;
-  const unsigned grid = (unsigned)((h->stride + kBlock - 1) / kBlock);
+  p.env_reward = h->buf.env_reward; p.done = h->buf.done; p.env_state = h->buf.env_state; p.err = h->err;
+  int nw; unsigned grid; size_t lds;
+  launch_geometry(h, h->use_table, &nw, &grid, &lds);
   DeviceGuard g(h->device);
   if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
-  hipLaunchKernelGGL(h->fn, dim3(grid), dim3(kBlock), h->lds_bytes, h->stream, p);
+  hipLaunchKernelGGL(h->use_table ? h->var->table : h->var->generic, dim3(grid), dim3(nw * kWave), lds, h->stream, p);
   HIP_TRY(hipGetLastError());
   return MG_OK;
-}
-
-template <int V>
-void vis_hook(const uint64_t* patterns, int64_t n, uint64_t* out) {
-  for (int64_t k = 0; k < n; ++k) {
-    const uint64_t pat = patterns[k];
-    uint64_t res = 0;
-    uint32_t opq[V], vis[V];
-    for (int j = 0; j < V; ++j) opq[j] = 0;
-    for (int i = 0; i < V; ++i)
-      for (int j = 0; j < V; ++j) opq[j] |= (uint32_t)((pat >> (i * V + j)) & 1u) << i;
-    mg_vis_rows<V>(opq, vis);
-    for (int i = 0; i < V; ++i)
-      for (int j = 0; j < V; ++j) res |= (uint64_t)((vis[j] >> i) & 1u) << (i * V + j);
-    out[k] = res;
-  }
 }
 
 }  // namespace
@@ -598,7 +813,7 @@ void vis_hook(const uint64_t* patterns, int64_t n, uint64_t* out) {
 extern "C" {
 
 const char* mg_last_error(void) { return g_err.c_str(); }
-const char* mg_version(void) { return "mgrid-hip 0.1 (gfx950)"; }
+const char* mg_version(void) { return "mgrid-hip 0.2 (gfx950)"; }
 
 int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (!cfg || !out) return fail(MG_EINVAL, "null argument");
@@ -610,12 +825,14 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (c.shaping_kind != MG_SHAPING_NONE && c.shaping_kind != MG_SHAPING_V8) return fail(MG_EINVAL, "unknown shaping_kind");
   if (c.action_dtype != MG_ACT_U8 && c.action_dtype != MG_ACT_I32 && c.action_dtype != MG_ACT_I64)
     return fail(MG_EINVAL, "unknown action_dtype");
+  if (c.kernel_path < MG_PATH_AUTO || c.kernel_path > MG_PATH_TABLE) return fail(MG_EINVAL, "unknown kernel_path");
   if (c.env_id_base < 0 || (uint64_t)c.env_id_base + (uint64_t)c.n_envs > 0xFFFFFFFFull)
     return fail(MG_EINVAL, "global env ids must fit 32 bits");
-  kernel_fn fn = nullptr;
+  const Variant* var = nullptr;
   for (const Variant& v : kVariants)
-    if (v.A == c.n_agents && v.V == c.view_size) fn = v.fn;
-  if (!fn) return fail(MG_EUNSUPPORTED, "no kernel instantiated for this (n_agents, view_size)");
+    if (v.A == c.n_agents && v.V == c.view_size) var = &v;
+  if (!var) return fail(MG_EUNSUPPORTED, "no kernel instantiated for this (n_agents, view_size)");
+  if (c.kernel_path == MG_PATH_TABLE && !var->table) return fail(MG_EUNSUPPORTED, "no table kernel for this view_size");
 
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
@@ -624,18 +841,25 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
 
   mg_handle* h = new mg_handle();
-  h->cfg = c; h->device = device; h->fn = fn; h->t = 0; h->have_map = h->have_reset = false;
+  h->cfg = c; h->device = device; h->var = var; h->t = 0; h->have_map = h->have_reset = false;
+  h->use_table = false; h->n_entries = 0; h->view_table = nullptr; h->cell_index = nullptr;
   h->stride = (c.n_envs + 63) / 64 * 64;
+  h->n_chunks = h->stride / 64;
   h->PW = c.width + 2 * (c.view_size - 1);
   h->PH = c.height + 2 * (c.view_size - 1);
   h->gx = h->gy = 13;
+  h->n_cu = 256;
+  (void)hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device);
+  if (h->n_cu < 1) h->n_cu = 1;
   const int rowb = c.view_size * c.view_size * 3;
-  h->lds_bytes = (size_t)(kBlock / kWave) * kWave * rowb + (size_t)c.width * c.height * 8 + (size_t)h->PW * h->PH * 4;
   h->own_stream = true;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail(MG_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-  if (e != hipSuccess) { (void)hipStreamDestroy(h->stream); delete h; return fail(MG_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
+  for (kernel_fn fn : {var->generic, var->table}) {
+    if (!fn) continue;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+    if (e != hipSuccess) { (void)hipStreamDestroy(h->stream); delete h; return fail(MG_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
+  }
 
   const size_t A = (size_t)c.n_agents, S = (size_t)h->stride;
   memset(&h->buf, 0, sizeof(h->buf));
@@ -643,15 +867,15 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (rc == MG_OK) rc = dalloc(h, &h->map_pad, (size_t)h->PW * h->PH);
   if (rc == MG_OK) rc = dalloc(h, &h->dist_lut, (size_t)c.width * c.height);
   if (rc == MG_OK) rc = dalloc(h, &h->reward_lut, (size_t)c.max_steps + 1);
+  if (rc == MG_OK) rc = dalloc(h, &h->cell_index, (size_t)c.width * c.height);
+  if (rc == MG_OK) rc = dalloc(h, &h->view_table, (size_t)c.width * c.height * 4 * (var->entw ? var->entw : 4));
   if (rc == MG_OK) rc = dalloc(h, &h->err, 1);
   if (rc == MG_OK) rc = dalloc(h, &h->buf.obs_image, A * S * rowb);
   if (rc == MG_OK) rc = dalloc(h, &h->buf.obs_dir, A * S);
   if (rc == MG_OK) rc = dalloc(h, &h->buf.reward, A * S);
   if (rc == MG_OK && c.emit_env_reward) rc = dalloc(h, &h->buf.env_reward, A * S);
   if (rc == MG_OK) rc = dalloc(h, &h->buf.done, S);
-  if (rc == MG_OK) rc = dalloc(h, &h->buf.agent_state, A * S);
-  if (rc == MG_OK) rc = dalloc(h, &h->buf.shaper_state, A * S);
-  if (rc == MG_OK) rc = dalloc(h, &h->buf.step_state, S);
+  if (rc == MG_OK) rc = dalloc(h, &h->buf.env_state, (A + 1) * S);
   if (rc == MG_OK) {
     // MiniGridEnv._reward() for every step count, computed with the host's float64 ops so that
     // the device returns exactly what CPython computes (multigrid.py:883)
@@ -687,16 +911,18 @@ int mg_destroy(mg_handle* h) {
 
 int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
   if (!h || !cells) return fail(MG_EINVAL, "null argument");
-  const int W = h->cfg.width, H = h->cfg.height, pad = h->cfg.view_size - 1;
+  const mg_config& cfg = h->cfg;
+  const int W = cfg.width, H = cfg.height, V = cfg.view_size, pad = V - 1;
   const uint32_t wall = (uint32_t)MG_T_WALL | (5u << 8) | F_OPAQUE;   // Grid.slice's out-of-bounds Wall() (multigrid.py:315)
   std::vector<uint32_t> m((size_t)h->PW * h->PH, wall);
-  int gx = -1, gy = -1;
+  std::vector<uint16_t> cidx((size_t)W * H, 0);
+  int gx = -1, gy = -1, n_free = 0;
   for (int y = 0; y < H; ++y)
     for (int x = 0; x < W; ++x) {
       const uint8_t* c = cells + ((size_t)y * W + x) * 3;
       uint32_t w = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
       switch (c[0]) {
-        case MG_T_EMPTY: w = (uint32_t)MG_T_EMPTY | F_FREE; break;
+        case MG_T_EMPTY: w = (uint32_t)MG_T_EMPTY | F_FREE; cidx[(size_t)y * W + x] = (uint16_t)n_free++; break;
         case MG_T_WALL: w |= F_OPAQUE; break;
         case MG_T_GOAL: w |= F_KILL | F_GOAL; break;
         case MG_T_LAVA: w |= F_KILL; break;
@@ -705,6 +931,7 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
       }
       m[(size_t)(y + pad) * h->PW + (x + pad)] = w;
     }
+  if (n_free < cfg.n_agents) return fail(MG_EINVAL, "fewer free cells than agents");
   // get_goal_position (v8_robust_ppo.py:159-169): first goal scanning x-major, else (13,13)
   for (int i = 0; i < W && gx < 0; ++i)
     for (int j = 0; j < H; ++j)
@@ -717,10 +944,39 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
       const long dx = x - gx, dy = y - gy;
       d[(size_t)y * W + x] = sqrt((double)(dx * dx + dy * dy));   // np.linalg.norm (v8:192)
     }
+  // Static view table: the view from every free cell in every direction (agents are transparent
+  // and nothing else moves on a static map, so slice+rotate+process_vis+encode of the static
+  // part is a pure function of (cell, dir)).
+  const Variant* var = h->var;
+  std::vector<uint32_t> table;
+  bool use_table = var->table != nullptr && cfg.kernel_path != MG_PATH_GENERIC;
+  if (use_table) {
+    h->n_entries = n_free * 4;
+    table.assign((size_t)h->n_entries * var->entw, 0u);
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        if (!(m[(size_t)(y + pad) * h->PW + (x + pad)] & F_FREE)) continue;
+        for (int dir = 0; dir < 4; ++dir) {
+          uint32_t* out = table.data() + ((size_t)cidx[(size_t)y * W + x] * 4 + dir) * var->entw;
+          if (V == 5) host_view_entry<5>(m, h->PW, pad, cfg.see_through_walls != 0, x, y, dir, out);
+          else host_view_entry<3>(m, h->PW, pad, cfg.see_through_walls != 0, x, y, dir, out);
+        }
+      }
+    // the table, the other LUTs and at least one wave's staging must fit the CU's LDS
+    const size_t need = lds_fixed_bytes(h, true) + (size_t)kWave * V * V * 3;
+    if (need > (size_t)kLdsLimit) {
+      if (cfg.kernel_path == MG_PATH_TABLE) return fail(MG_EUNSUPPORTED, "view table does not fit LDS for this map");
+      use_table = false;
+    }
+  }
+  if (!use_table) h->n_entries = 0;
   DeviceGuard g(h->device);
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(h->map_pad, m.data(), m.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->dist_lut, d.data(), d.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->cell_index, cidx.data(), cidx.size() * 2, hipMemcpyHostToDevice));
+  if (use_table) HIP_TRY(hipMemcpy(h->view_table, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+  h->use_table = use_table;
   h->have_map = true;
   return MG_OK;
 }
@@ -729,8 +985,7 @@ int mg_reset(mg_handle* h, const uint8_t* env_mask) {
   if (!h) return fail(MG_EINVAL, "null handle");
   if (!h->have_map) return fail(MG_ESTATE, "mg_set_static_map must be called before mg_reset");
   int rc = launch(h, OP_RESET, nullptr, nullptr, nullptr, nullptr, env_mask, 0, nullptr);
-  if (rc == MG_OK && !env_mask) h->have_reset = true;
-  if (rc == MG_OK && env_mask) h->have_reset = true;
+  if (rc == MG_OK) h->have_reset = true;
   return rc;
 }
 
@@ -820,6 +1075,18 @@ int mg_check_errors(mg_handle* h, uint32_t* out) {
 int mg_get_goal(mg_handle* h, int32_t* gx, int32_t* gy) {
   if (!h || !gx || !gy) return fail(MG_EINVAL, "null argument");
   *gx = h->gx; *gy = h->gy;
+  return MG_OK;
+}
+
+// Which kernel path the handle runs (MG_PATH_GENERIC or MG_PATH_TABLE) and its launch geometry.
+int mg_get_launch_info(mg_handle* h, int32_t* path, int32_t* block_threads, int32_t* grid_blocks, int32_t* lds_bytes) {
+  if (!h) return fail(MG_EINVAL, "null handle");
+  int nw; unsigned grid; size_t lds;
+  launch_geometry(h, h->use_table, &nw, &grid, &lds);
+  if (path) *path = h->use_table ? MG_PATH_TABLE : MG_PATH_GENERIC;
+  if (block_threads) *block_threads = nw * kWave;
+  if (grid_blocks) *grid_blocks = (int32_t)grid;
+  if (lds_bytes) *lds_bytes = (int32_t)lds;
   return MG_OK;
 }
 

@@ -156,11 +156,11 @@ class OracleEnv:
 
   @property
   def agent_pos(self):
-    return [np.array([s & 255, (s >> 8) & 255]) for s in self.agent_states()]
+    return [np.array([s & 63, (s >> 6) & 63]) for s in self.agent_states()]
 
   @property
   def agent_dir(self):
-    return [(s >> 16) & 3 for s in self.agent_states()]
+    return [(s >> 12) & 3 for s in self.agent_states()]
 
   def agent_states(self):
     return [self.L.mgo_agent_state(self.h, a) for a in range(self.A)]

