@@ -98,7 +98,7 @@ def main():
                                    shaping='v8', auto_reset=True)
   gen = torch.Generator(device=dev)
   gen.manual_seed(1234 + rank)
-  ring = torch.randint(0, 7, (ACTION_RING, env.n_agents, env.stride), dtype=torch.uint8, device=dev, generator=gen)
+  ring = torch.randint(0, 7, (ACTION_RING, env.stride, 4), dtype=torch.uint8, device=dev, generator=gen)
   env.reset()
 
   def run(k):

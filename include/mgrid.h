@@ -17,10 +17,15 @@
  *  - a handle is bound to one HIP device and one stream.  Calls on one handle are not
  *    re-entrant; different handles may be driven from different host threads.
  *  - reset/step calls are asynchronous on the handle's stream; mg_sync() blocks.
- *  - all per-env arrays are AGENT-MAJOR: element (agent a, env n) lives at a*env_stride + n,
- *    where env_stride = mg_buffers.env_stride (n_envs rounded up to a multiple of 64).
- *    This mirrors the reference's obs dict, whose 'image'/'direction' entries are lists
- *    indexed by agent first (multigrid.py:1060-1063).
+ *  - env_stride = mg_buffers.env_stride = n_envs rounded up to a multiple of 64; every array is
+ *    allocated (by the library) or expected (from the caller) with env_stride env slots.
+ *  - the big outputs are AGENT-MAJOR: obs_image and reward put element (agent a, env n) at
+ *    a*env_stride + n, mirroring the reference's obs dict whose 'image' entry is a list indexed
+ *    by agent first (multigrid.py:1060-1063) and giving each per-agent policy network a
+ *    contiguous [N, ...] tensor.
+ *  - small per-env records are ENV-MAJOR, one naturally aligned word per env so that a wavefront
+ *    moves them with one coalesced instruction: actions (4 bytes), order (4 bytes), dir_done
+ *    (4 or 8 bytes), env_state (A+1 dwords), respawn/spawn (A dwords).
  *  - the library owns all device buffers; mg_get_buffers() hands out borrowed device
  *    pointers that stay valid until mg_destroy().
  */
@@ -50,11 +55,6 @@ extern "C" {
 #define MG_PATH_AUTO    0
 #define MG_PATH_GENERIC 1
 #define MG_PATH_TABLE   2
-
-/* action_dtype */
-#define MG_ACT_U8  1
-#define MG_ACT_I32 4
-#define MG_ACT_I64 8
 
 /* cell encoding = gym-minigrid OBJECT_TO_IDX / COLOR_TO_IDX / door state */
 #define MG_T_UNSEEN 0
@@ -90,7 +90,7 @@ typedef struct mg_config {
                                 kernel and the obs written is the post-reset obs (gym vector
                                 autoreset; v7_stable_goal_focused_ppo.py:334-340 is the only
                                 reference precedent).  0: reference behaviour, caller resets. */
-  int32_t action_dtype;      /* MG_ACT_* : element type of the actions array */
+  int32_t reserved0;
   int32_t emit_env_reward;   /* 1: also write the unshaped env reward (mg_buffers.env_reward) */
   int32_t kernel_path;       /* MG_PATH_AUTO (default), or force MG_PATH_GENERIC / MG_PATH_TABLE */
   int64_t n_envs;            /* envs held by THIS handle (this GPU's shard) */
@@ -106,10 +106,12 @@ typedef struct mg_buffers {
   int32_t  obs_cell_bytes; /* V*V*3 : bytes of one agent's image, [vx][vy][(type,color,state)]
                               exactly as Grid.encode lays it out */
   uint8_t* obs_image;    /* [A][env_stride][V*V*3]  — obs['image'][a]   */
-  uint8_t* obs_dir;      /* [A][env_stride]         — obs['direction'][a] */
   double*  reward;       /* [A][env_stride]  rewards[a] (shaped when shaping_kind != NONE) */
   double*  env_reward;   /* [A][env_stride]  unshaped env reward, NULL unless emit_env_reward */
-  uint8_t* done;         /* [env_stride]     collective done of the step just taken */
+  uint8_t* dir_done;     /* [env_stride][dir_done_bytes]: byte a = obs['direction'][a] (a < A), byte A =
+                            collective done of the step just taken; dir_done_bytes = 4 (A <= 3) or 8 */
+  int32_t  dir_done_bytes;
+  int32_t  reserved;
   uint32_t* env_state;   /* [env_stride][A+1]: words 0..A-1 = one word per agent
                               x:6 | y:6<<6 | dir:2<<12 | prev_x:6<<14 | prev_y:6<<20 | valid<<26 | stationary:3<<27
                             (post-step, post-respawn position = what v8 reads as env.agent_pos[a], v8:242;
@@ -140,18 +142,19 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells);
 int mg_reset(mg_handle* h, const uint8_t* env_mask);
 
 /* Same, with the spawn the reference's time-seeded RNG would have produced injected:
- * spawn = device pointer int8[A][env_stride][4] = (x, y, dir, 0) (cluttered.py:55-63). */
+ * spawn = device pointer int8[env_stride][A][4] = (x, y, dir, 0) (cluttered.py:55-63). */
 int mg_reset_inject(mg_handle* h, const uint8_t* env_mask, const int8_t* spawn);
 
 /* env.step(actions) (multigrid.py:963-995) for all envs, free-running: the agent order
  * (multigrid.py:973-974) and respawns (multigrid.py:815-832) are drawn on device (Philox).
- * actions = device pointer [A][env_stride] of cfg.action_dtype. */
+ * actions = device pointer uint8[env_stride][4]: byte a of env n = action of agent a in [0,6]
+ * (the list `env.step(actions)` takes, multigrid.py:963-978); bytes >= A are ignored. */
 int mg_step(mg_handle* h, const void* actions);
 
 /* env.step(actions) with the reference's two RNG streams injected (bit-exact replay):
- *   order   = device uint8[A][env_stride]: order[k][n] = agent acting k-th (the shuffled
+ *   order   = device uint8[env_stride][4]: byte k of env n = agent acting k-th (the shuffled
  *             np.arange of multigrid.py:973-974)
- *   respawn = device int8[A][env_stride][4] = (x,y,dir,0) accepted by place_one_agent for
+ *   respawn = device int8[env_stride][A][4] = (x,y,dir,0) accepted by place_one_agent for
  *             agent a if it finishes this step (multigrid.py:832), x = -1 if none recorded
  *   reset_spawn = same layout, used when auto_reset fires; may be NULL when auto_reset == 0 */
 int mg_step_replay(mg_handle* h, const void* actions, const uint8_t* order,
@@ -159,7 +162,7 @@ int mg_step_replay(mg_handle* h, const void* actions, const uint8_t* order,
 
 /* Synthetic-rollout step: like mg_step but the actions are drawn on device too
  * (uniform in [0,6], the "random actions" of BASELINE.json configs) and also stored to
- * `actions_out` (device [A][env_stride] uint8, may be NULL). */
+ * `actions_out` (device uint8[env_stride][4], same layout as `actions`; may be NULL). */
 int mg_step_random(mg_handle* h, uint8_t* actions_out);
 
 int mg_get_buffers(mg_handle* h, mg_buffers* out);
@@ -184,6 +187,10 @@ int mg_get_goal(mg_handle* h, int32_t* gx, int32_t* gy);
 /* Kernel path actually in use (MG_PATH_GENERIC / MG_PATH_TABLE) and its launch geometry; any
  * out pointer may be NULL.  No reference counterpart (diagnostics for DESIGN.md / bench.py). */
 int mg_get_launch_info(mg_handle* h, int32_t* path, int32_t* block_threads, int32_t* grid_blocks, int32_t* lds_bytes);
+
+/* Test hook (no reference counterpart): MiniGridEnv._reward() = 1 - 0.9*(s/max_steps) as the
+ * DEVICE computes it, for s = 0..max_steps, copied to host `out` (max_steps+1 doubles). */
+int mg_debug_device_rewards(int device, int32_t max_steps, double* out);
 
 /* Test hook, host only (no GPU call, no reference counterpart): evaluates the kernels' bitmask
  * form of Grid.process_vis on n opacity patterns so that it can be compared

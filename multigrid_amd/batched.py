@@ -27,12 +27,11 @@ def _alias(ptr, shape, typestr, device):
   return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device)
 
 
-_ACT = {'u8': (_lib.ACT_U8, torch.uint8), 'i32': (_lib.ACT_I32, torch.int32), 'i64': (_lib.ACT_I64, torch.int64)}
 
 
 class BatchedMultiGrid:
   def __init__(self, cells, n_envs, n_agents=3, view_size=5, max_steps=100, see_through_walls=False,
-               competitive=False, shaping='v8', auto_reset=True, action_dtype='u8', device=0, seed=0,
+               competitive=False, shaping='v8', auto_reset=True, device=0, seed=0,
                env_id_base=0, emit_env_reward=False, use_torch_stream=True, kernel_path='auto'):
     self.L = _lib.load()
     cells = np.ascontiguousarray(cells, dtype=np.uint8)
@@ -41,12 +40,11 @@ class BatchedMultiGrid:
     self.n_envs, self.n_agents, self.view_size, self.max_steps = int(n_envs), int(n_agents), int(view_size), int(max_steps)
     self.device_index = int(device)
     self.device = torch.device('cuda', self.device_index)
-    self.act_code, self.act_torch = _ACT[action_dtype]
     cfg = _lib.MgConfig(
         width=self.width, height=self.height, n_agents=n_agents, view_size=view_size, max_steps=max_steps,
         see_through_walls=int(see_through_walls), competitive=int(competitive),
         shaping_kind={None: 0, 'none': 0, 'v8': 1}[shaping], auto_reset=int(auto_reset),
-        action_dtype=self.act_code, emit_env_reward=int(emit_env_reward),
+        reserved0=0, emit_env_reward=int(emit_env_reward),
         kernel_path={'auto': 0, 'generic': 1, 'table': 2}[kernel_path],
         n_envs=n_envs, env_id_base=env_id_base, seed=seed)
     self.h = C.c_void_p()
@@ -63,20 +61,20 @@ class BatchedMultiGrid:
     A, V, n, dev = self.n_agents, self.view_size, self.n_envs, self.device
     # full-stride tensors (what the kernels address) ...
     self._obs_image = _alias(b.obs_image, (A, S, V, V, 3), '|u1', dev)
-    self._obs_dir = _alias(b.obs_dir, (A, S), '|u1', dev)
+    self._dir_done = _alias(b.dir_done, (S, int(b.dir_done_bytes)), '|u1', dev)
     self._reward = _alias(b.reward, (A, S), '<f8', dev)
     self._env_reward = _alias(b.env_reward, (A, S), '<f8', dev) if b.env_reward else None
-    self._done = _alias(b.done, (S,), '|u1', dev)
     self._env_state = _alias(b.env_state, (S, A + 1), '<i4', dev)
     # ... and the [:, :n_envs] views callers use
     self.obs_image = self._obs_image[:, :n]      # obs['image'][a]     uint8[A, N, V, V, 3]
-    self.obs_dir = self._obs_dir[:, :n]          # obs['direction'][a] uint8[A, N]
+    self.obs_dir = self._dir_done[:n, :A].t()    # obs['direction'][a] uint8[A, N] (strided view)
     self.reward = self._reward[:, :n]            # rewards[a]          float64[A, N]
     self.env_reward = None if self._env_reward is None else self._env_reward[:, :n]
-    self.done = self._done[:n]                   # collective done     uint8[N]
+    self.done = self._dir_done[:n, A]            # collective done     uint8[N]    (strided view)
     self.env_state = self._env_state[:n]         # int32[N, A+1], packing in include/mgrid.h
-    # action staging buffer in the layout the kernel reads
-    self.actions = torch.zeros((A, S), dtype=self.act_torch, device=dev)
+    # action buffer in the layout the kernel reads: one dword per env, byte a = agent a's action.
+    # Policies write `env.actions[:N, a]`; `step()` with no argument consumes it.
+    self.actions = torch.full((S, 4), 6, dtype=torch.uint8, device=dev)
     gx, gy = C.c_int32(), C.c_int32()
     _lib.check(self.L.mg_get_goal(self.h, C.byref(gx), C.byref(gy)))
     self.goal_pos = (gx.value, gy.value)
@@ -94,21 +92,23 @@ class BatchedMultiGrid:
       pass
 
   # ---- helpers ------------------------------------------------------------------------------
-  def _dev_ptr(self, t, dtype, shape_tail=()):
-    """Device pointer of `t` laid out [A, stride, *tail]; copies into a padded buffer if needed."""
+  def _env_major(self, t, dtype, width, tail=()):
+    """Device tensor [stride, width, *tail] from agent-major input [A, N|stride, *tail]
+    (or pass-through when it already has the kernel layout)."""
     if t is None:
       return None, None
     t = torch.as_tensor(t, device=self.device)
     if t.dtype != dtype:
       t = t.to(dtype)
-    full = (self.n_agents, self.stride) + tuple(shape_tail)
-    if tuple(t.shape) != full:
-      assert tuple(t.shape) == (self.n_agents, self.n_envs) + tuple(shape_tail), (tuple(t.shape), full)
-      buf = torch.zeros(full, dtype=dtype, device=self.device)
-      buf[:, :self.n_envs] = t
-      t = buf
-    t = t.contiguous()
-    return C.c_void_p(t.data_ptr()), t
+    full = (self.stride, width) + tuple(tail)
+    if tuple(t.shape) == full:
+      t = t.contiguous()
+      return C.c_void_p(t.data_ptr()), t
+    assert t.shape[0] == self.n_agents and t.shape[1] in (self.n_envs, self.stride), (tuple(t.shape), full)
+    buf = torch.zeros(full, dtype=dtype, device=self.device)
+    m = t.shape[1]
+    buf[:m, :self.n_agents] = t.transpose(0, 1)
+    return C.c_void_p(buf.data_ptr()), buf
 
   def _mask_ptr(self, mask):
     if mask is None:
@@ -116,6 +116,12 @@ class BatchedMultiGrid:
     m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
     assert m.numel() >= self.n_envs
     return C.c_void_p(m.data_ptr()), m
+
+  def _actions_ptr(self, actions):
+    t = torch.as_tensor(actions, device=self.device)
+    if t.dtype != torch.uint8:
+      t = t.clamp(0, 255).to(torch.uint8)     # anything outside [0,6] is reported as MG_ERR_BAD_ACTION
+    return self._env_major(t, torch.uint8, 4)
 
   def obs(self):
     return {'image': self.obs_image, 'direction': self.obs_dir}
@@ -157,24 +163,25 @@ class BatchedMultiGrid:
     if spawn is None:
       _lib.check(self.L.mg_reset(self.h, mp))
     else:
-      sp, _s = self._dev_ptr(spawn, torch.int8, (4,))
+      sp, _s = self._env_major(spawn, torch.int8, self.n_agents, (4,))
       _lib.check(self.L.mg_reset_inject(self.h, mp, sp))
     return self.obs()
 
   def step(self, actions=None):
-    """env.step(actions): actions [A, N] (or the preloaded self.actions when None)."""
+    """env.step(actions): actions uint8 [stride, 4] (kernel layout, zero copy), or agent-major
+    [A, N] of any integer dtype (copied), or None to consume the preloaded self.actions."""
     if actions is None:
       ap, _a = C.c_void_p(self.actions.data_ptr()), self.actions
     else:
-      ap, _a = self._dev_ptr(actions, self.act_torch)
+      ap, _a = self._actions_ptr(actions)
     _lib.check(self.L.mg_step(self.h, ap))
     return self.obs(), self.reward, self.done, {}
 
   def step_replay(self, actions, order, respawn, reset_spawn=None):
-    ap, _a = self._dev_ptr(actions, self.act_torch)
-    op, _o = self._dev_ptr(order, torch.uint8)
-    rp, _r = self._dev_ptr(respawn, torch.int8, (4,))
-    sp, _s = self._dev_ptr(reset_spawn, torch.int8, (4,))
+    ap, _a = self._actions_ptr(actions)
+    op, _o = self._env_major(order, torch.uint8, 4)
+    rp, _r = self._env_major(respawn, torch.int8, self.n_agents, (4,))
+    sp, _s = self._env_major(reset_spawn, torch.int8, self.n_agents, (4,))
     _lib.check(self.L.mg_step_replay(self.h, ap, op, rp, sp))
     return self.obs(), self.reward, self.done, {}
 
@@ -182,7 +189,7 @@ class BatchedMultiGrid:
     """One step with on-device uniform random actions (synthetic rollouts)."""
     ptr = None
     if actions_out is not None:
-      assert actions_out.dtype == torch.uint8 and tuple(actions_out.shape) == (self.n_agents, self.stride)
+      assert actions_out.dtype == torch.uint8 and tuple(actions_out.shape) == (self.stride, 4)
       ptr = C.c_void_p(actions_out.data_ptr())
     _lib.check(self.L.mg_step_random(self.h, ptr))
     return self.obs(), self.reward, self.done, {}

@@ -49,7 +49,7 @@ class RefCompatEnv:
   def step(self, actions):
     if not isinstance(actions, (list, tuple, np.ndarray)) and self.n_agents == 1:
       actions = [actions]                       # multigrid.py:965-966
-    a = torch.as_tensor(np.asarray(actions).reshape(self.n_agents, 1), device=self.b.device)
+    a = torch.as_tensor(np.asarray(actions, dtype=np.int64).reshape(self.n_agents, 1), device=self.b.device)
     self.b.step(a)
     rew = self.b.reward[:, 0].cpu().numpy()
     done = bool(self.b.done[0].item())

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <algorithm>
@@ -63,27 +64,25 @@ template <int V> struct ViewGeom {
 };
 
 struct Params {
-  int32_t W, H, max_steps, see_through, competitive, shaping, auto_reset, act_elem;
+  int32_t W, H, max_steps, see_through, competitive, shaping, auto_reset, dd_bytes;
   int32_t op, random_actions, PW, PH, n_entries, reserved;
   int64_t n_envs, stride, n_chunks;
   uint64_t gid_base, t;
   uint32_t seed_lo, seed_hi;
   const uint32_t* map_pad;     // [PH][PW]
   const double* dist_lut;      // [H][W] distance to the shaper's goal cell
-  const double* reward_lut;    // [max_steps+1]
   const uint32_t* view_table;  // [n_entries][ENTW] (table path) : static view of (free cell, dir)
   const uint16_t* cell_index;  // [H][W] -> free-cell index (table path)
-  const void* actions;
-  const uint8_t* order;
-  const uint32_t* respawn;     // int8x4 per (agent, env)
-  const uint32_t* reset_spawn; // int8x4 per (agent, env)
+  const uint32_t* actions;     // u8x4 per env
+  const uint32_t* order;       // u8x4 per env
+  const uint32_t* respawn;     // int8x4 per (env, agent)
+  const uint32_t* reset_spawn; // int8x4 per (env, agent)
   const uint8_t* mask;
-  uint8_t* actions_out;
+  uint32_t* actions_out;       // u8x4 per env
   uint8_t* obs_image;
-  uint8_t* obs_dir;
   double* reward;
   double* env_reward;
-  uint8_t* done;
+  uint8_t* dir_done;           // [stride][dd_bytes]: dir of agent a at byte a, done at byte A
   uint32_t* env_state;         // [stride][A+1]
   uint32_t* err;
 };
@@ -102,6 +101,16 @@ __device__ __forceinline__ U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   return U4{c0, c1, c2, c3};
+}
+
+// MiniGridEnv._reward() = 1 - 0.9 * (step_count / max_steps) in IEEE
+// float64 with one rounding per operation (-ffp-contract=off; hipcc's f64 division is the
+// correctly rounded v_div_scale/v_div_fmas/v_div_fixup sequence).  Checked against CPython's
+// value for every step count in tests/test_gpu_parity.py::test_device_reward_values.
+__device__ __forceinline__ double device_reward(uint32_t step, int max_steps) {
+  const double q = (double)step / (double)max_steps;
+  const double m = 0.9 * q;
+  return 1.0 - m;
 }
 
 // Per-agent values that are selected with a RUN-TIME agent id live in packed integers and are
@@ -138,7 +147,7 @@ __device__ __forceinline__ uint32_t place_agent(const Params& p, const uint32_t*
   int x = -1, y = -1, dir = 0;
   uint32_t err = 0;
   if (inj) {
-    const uint32_t w = inj[(int64_t)a * p.stride + n];
+    const uint32_t w = inj[n * A + a];
     x = (int8_t)(w & 255u); y = (int8_t)((w >> 8) & 255u); dir = (int8_t)((w >> 16) & 255u);
     if (x < 0) { err = MG_ERR_MISSING_DRAW; x = -1; }
     else if (!cell_free<A>(p, map, pd, occ, x, y) || (unsigned)dir > 3u) { err = MG_ERR_BAD_RESPAWN; x = -1; }
@@ -314,17 +323,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct ChunkIn {
   u32x4 q;          // A == 3: the four env_state words
   uint32_t w[5];    // other A: env_state words, compile-time indices only
-  uint32_t act[4];  // raw actions (low 32 bits for 64-bit actions)
+  uint32_t act;     // the env's four action bytes, as loaded
 };
 
 __device__ __forceinline__ uint32_t asm_load_u32(const void* ptr) {
   uint32_t v;
   asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(ptr) : "memory");
-  return v;
-}
-__device__ __forceinline__ uint32_t asm_load_u8(const void* ptr) {
-  uint32_t v;
-  asm volatile("global_load_ubyte %0, %1, off" : "=&v"(v) : "v"(ptr) : "memory");
   return v;
 }
 
@@ -334,8 +338,7 @@ __device__ __forceinline__ void load_chunk(const Params& p, int64_t env0, int la
   in.q = u32x4{0, 0, 0, 0};
 #pragma unroll
   for (int a = 0; a < 5; ++a) in.w[a] = 0u;
-#pragma unroll
-  for (int a = 0; a < 4; ++a) in.act[a] = 6u;
+  in.act = 0x06060606u;
   if (A == 3) {
     const void* ptr = reinterpret_cast<const uint4*>(p.env_state) + n;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(in.q) : "v"(ptr) : "memory");
@@ -343,27 +346,18 @@ __device__ __forceinline__ void load_chunk(const Params& p, int64_t env0, int la
 #pragma unroll
     for (int a = 0; a <= A; ++a) in.w[a] = asm_load_u32(p.env_state + n * (A + 1) + a);
   }
-  if (p.op == OP_STEP && !p.random_actions) {
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-      const int64_t i = (int64_t)a * p.stride + n;
-      if (p.act_elem == MG_ACT_U8) in.act[a] = asm_load_u8(static_cast<const uint8_t*>(p.actions) + i);
-      else if (p.act_elem == MG_ACT_I32) in.act[a] = asm_load_u32(static_cast<const uint32_t*>(p.actions) + i);
-      else in.act[a] = asm_load_u32(static_cast<const uint32_t*>(p.actions) + 2 * i);   // little-endian low half
-    }
-  }
+  if (p.op == OP_STEP && !p.random_actions) in.act = asm_load_u32(p.actions + n);
 }
 
 // Retire the loads of load_chunk: at most K vector-memory operations younger than them may stay
 // in flight.  The registers are operands so that no use (not even a copy) can be moved above it.
 template <int K>
 __device__ __forceinline__ void wait_chunk(ChunkIn& in) {
-  asm volatile("s_waitcnt vmcnt(%9)"
+  asm volatile("s_waitcnt vmcnt(%7)"
                : "+v"(in.q), "+v"(in.w[0]), "+v"(in.w[1]), "+v"(in.w[2]), "+v"(in.w[3]), "+v"(in.w[4]),
-                 "+v"(in.act[0]), "+v"(in.act[1]), "+v"(in.act[2])
+                 "+v"(in.act)
                : "n"(K)
                : "memory");
-  asm volatile("" : "+v"(in.act[3]));
 }
 
 // One chunk (64 envs) of one step()/reset().
@@ -388,7 +382,7 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
   uint32_t actw = 0, st = win[A], err = 0;
 #pragma unroll
   for (int a = 0; a < A; ++a) {
-    actw |= min(in.act[a], 7u) << (3 * a);
+    actw |= min((in.act >> (8 * a)) & 255u, 7u) << (3 * a);
     // keep every later LDS index in range whatever the buffer holds
     const uint32_t w = win[a];
     const uint32_t cx = min(w & 63u, (uint32_t)(p.W - 1)), cy = min((w >> 6) & 63u, (uint32_t)(p.H - 1));
@@ -406,8 +400,10 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
 #pragma unroll
       for (int a = 0; a < A; ++a) actw |= __umulhi(rr[a & 3], 7u) << (3 * a);
       if (p.actions_out && active) {
+        uint32_t w = 0;
 #pragma unroll
-        for (int a = 0; a < A; ++a) p.actions_out[(int64_t)a * p.stride + n] = (uint8_t)((actw >> (3 * a)) & 7u);
+        for (int a = 0; a < A; ++a) w |= ((actw >> (3 * a)) & 7u) << (8 * a);
+        p.actions_out[n] = w;
       }
     }
     // ---- step_count += 1 (multigrid.py:968) ----------------------------------------------
@@ -421,9 +417,10 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
     for (int k = 0; k < A; ++k) ordw |= (uint32_t)k << (2 * k);
     if (p.order) {
       uint32_t seen = 0, w = 0;
+      const uint32_t ow = p.order[n];
 #pragma unroll
       for (int k = 0; k < A; ++k) {
-        const uint32_t o = p.order[(int64_t)k * p.stride + n];
+        const uint32_t o = (ow >> (8 * k)) & 255u;
         if (o < (uint32_t)A) seen |= 1u << o;
         w |= (o & 3u) << (2 * k);
       }
@@ -473,7 +470,7 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
     }
     // _reward() (multigrid.py:883): the same value for every agent that touched the goal this step
     double rgoal = 0.0;
-    if (gbits) rgoal = (step <= (uint32_t)p.max_steps) ? p.reward_lut[step] : 1.0 - 0.9 * ((double)step / (double)p.max_steps);
+    if (gbits) rgoal = device_reward(step, p.max_steps);
 
     // ---- collective done (multigrid.py:986-993) -------------------------------------------
     done_flag = (p.competitive && dbits != 0u) || (step >= (uint32_t)p.max_steps);
@@ -525,7 +522,6 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
         p.reward[i] = out_rew[a];
         if (p.env_reward) p.env_reward[i] = rew[a];
       }
-      p.done[n] = (uint8_t)done_flag;
     }
   }
 
@@ -556,9 +552,12 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
       for (int a = 0; a < A; ++a) p.env_state[n * (A + 1) + a] = wout[a];
       p.env_state[n * (A + 1) + A] = st;
     }
+    // obs['direction'][a] (multigrid.py:1083) for every agent + the collective done flag: one store
+    uint64_t dd = (uint64_t)done_flag << (8 * A);
 #pragma unroll
-    for (int a = 0; a < A; ++a)
-      p.obs_dir[(int64_t)a * p.stride + n] = (uint8_t)aw_d(pd_get(pd, a));   // obs['direction'][a] (multigrid.py:1083)
+    for (int a = 0; a < A; ++a) dd |= (uint64_t)aw_d(pd_get(pd, a)) << (8 * a);
+    if (A + 1 <= 4) reinterpret_cast<uint32_t*>(p.dir_done)[n] = (uint32_t)dd;
+    else reinterpret_cast<uint64_t*>(p.dir_done)[n] = dd;
     err_acc |= err;
   }
 
@@ -588,6 +587,13 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
   uint16_t* cidx = reinterpret_cast<uint16_t*>(map + p.PW * p.PH);
 
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
+  // persistent: each wave strides over the 64-env chunks on its own; the first chunk's inputs
+  // are requested before the LDS tables are filled
+  const int64_t cstride = (int64_t)gridDim.x * nw;
+  int64_t c = (int64_t)blockIdx.x * nw + wv;
+  ChunkIn cur, nxt;
+  if (c < p.n_chunks) load_chunk<A>(p, c * kWave, lane, cur);
+
   if (TAB) {
     const uint4* src = reinterpret_cast<const uint4*>(p.view_table);
     uint4* dst = reinterpret_cast<uint4*>(table);
@@ -600,28 +606,23 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
 
   uint32_t* stage = stage_all + wv * (kWave * ROWB / 4);
   uint32_t err = 0;
-  // persistent: each wave strides over the chunks on its own (no further workgroup barrier);
-  // the next chunk's inputs are requested before this chunk's stores are issued
-  const int64_t cstride = (int64_t)gridDim.x * nw;
-  int64_t c = (int64_t)blockIdx.x * nw + wv;
-  // vector-memory operations every iteration issues AFTER its prefetch (lower bound: the obs stores)
+  // Vector-memory operations an iteration issues AFTER its prefetch, every one of them for at
+  // least one lane of the wave (each chunk has an active lane): obs stores, then env_state and
+  // dir_done, and in a step the A reward stores.  A lower bound is all wait_chunk needs.
 #if MG_ABL == 0
-  constexpr int kYounger = (A * ((4 * ROWB + kWave - 1) / kWave)) < 63 ? (A * ((4 * ROWB + kWave - 1) / kWave)) : 63;
+  constexpr int kObs = A * ((4 * ROWB + kWave - 1) / kWave);
 #else
-  constexpr int kYounger = 0;
+  constexpr int kObs = 0;
 #endif
-  ChunkIn cur, nxt;
-  if (c < p.n_chunks) {
-    load_chunk<A>(p, c * kWave, lane, cur);
-    wait_chunk<0>(cur);
-  }
+  constexpr int kStep = (kObs + 2 + A) < 63 ? (kObs + 2 + A) : 63, kReset = (kObs + 2) < 63 ? (kObs + 2) : 63;
+  if (c < p.n_chunks) wait_chunk<0>(cur);
   for (; c < p.n_chunks; c += cstride) {
     const int64_t cn = c + cstride;
     const bool more = cn < p.n_chunks;          // wave-uniform
     if (more) load_chunk<A>(p, cn * kWave, lane, nxt);
     do_chunk<A, V, TAB>(p, map, dist, table, cidx, stage, lane, c * kWave, cur, err);
     if (more) {
-      wait_chunk<kYounger>(nxt);
+      if (p.op == OP_STEP) wait_chunk<kStep>(nxt); else wait_chunk<kReset>(nxt);
       cur = nxt;
     }
   }
@@ -717,14 +718,13 @@ struct mg_handle {
   bool use_table;
   int n_entries;
   int64_t stride, n_chunks;
-  int PW, PH, n_cu;
+  int PW, PH, n_cu, dd_bytes;
   bool have_map, have_reset;
   uint64_t t;
   int gx, gy;
   // device memory
   uint32_t* map_pad;
   double* dist_lut;
-  double* reward_lut;
   uint32_t* view_table;
   uint16_t* cell_index;
   uint32_t* err;
@@ -769,6 +769,7 @@ void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid
   const int rowb = h->cfg.view_size * h->cfg.view_size * 3;
   const size_t fixed = lds_fixed_bytes(h, table), per_wave = (size_t)kWave * rowb;
   int nw = table ? 16 : 4;
+  if (const char* e = getenv("MG_DEBUG_NW")) nw = atoi(e);   // tuning experiments only
   while (nw > 1 && (fixed + nw * per_wave > (size_t)kLdsLimit || h->n_chunks < (int64_t)h->n_cu * nw)) nw >>= 1;
   const size_t lds = fixed + nw * per_wave;
   int per_cu = (int)((size_t)kLdsLimit / lds);
@@ -786,19 +787,20 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   const mg_config& c = h->cfg;
   p.W = c.width; p.H = c.height; p.max_steps = c.max_steps; p.see_through = c.see_through_walls;
   p.competitive = (c.n_agents == 1) ? 1 : c.competitive;   // multigrid.py:380-381
-  p.shaping = c.shaping_kind; p.auto_reset = c.auto_reset; p.act_elem = c.action_dtype;
+  p.shaping = c.shaping_kind; p.auto_reset = c.auto_reset; p.dd_bytes = h->dd_bytes;
   p.op = op; p.random_actions = random_actions; p.PW = h->PW; p.PH = h->PH; p.n_entries = h->n_entries;
   p.n_envs = c.n_envs; p.stride = h->stride; p.n_chunks = h->n_chunks;
   p.gid_base = (uint64_t)c.env_id_base; p.t = h->t;
   p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32);
-  p.map_pad = h->map_pad; p.dist_lut = h->dist_lut; p.reward_lut = h->reward_lut;
+  p.map_pad = h->map_pad; p.dist_lut = h->dist_lut;
   p.view_table = h->view_table; p.cell_index = h->cell_index;
-  p.actions = actions; p.order = order;
+  p.actions = reinterpret_cast<const uint32_t*>(actions);
+  p.order = reinterpret_cast<const uint32_t*>(order);
   p.respawn = reinterpret_cast<const uint32_t*>(respawn);
   p.reset_spawn = reinterpret_cast<const uint32_t*>(reset_spawn);
-  p.mask = mask; p.actions_out = actions_out;
-  p.obs_image = h->buf.obs_image; p.obs_dir = h->buf.obs_dir; p.reward = h->buf.reward;
-  p.env_reward = h->buf.env_reward; p.done = h->buf.done; p.env_state = h->buf.env_state; p.err = h->err;
+  p.mask = mask; p.actions_out = reinterpret_cast<uint32_t*>(actions_out);
+  p.obs_image = h->buf.obs_image; p.reward = h->buf.reward;
+  p.env_reward = h->buf.env_reward; p.dir_done = h->buf.dir_done; p.env_state = h->buf.env_state; p.err = h->err;
   int nw; unsigned grid; size_t lds;
   launch_geometry(h, h->use_table, &nw, &grid, &lds);
   DeviceGuard g(h->device);
@@ -823,8 +825,6 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (c.n_envs < 1) return fail(MG_EINVAL, "n_envs must be >= 1");
   if (c.max_steps < 1 || c.max_steps > 65534) return fail(MG_EINVAL, "max_steps must be in [1,65534]");
   if (c.shaping_kind != MG_SHAPING_NONE && c.shaping_kind != MG_SHAPING_V8) return fail(MG_EINVAL, "unknown shaping_kind");
-  if (c.action_dtype != MG_ACT_U8 && c.action_dtype != MG_ACT_I32 && c.action_dtype != MG_ACT_I64)
-    return fail(MG_EINVAL, "unknown action_dtype");
   if (c.kernel_path < MG_PATH_AUTO || c.kernel_path > MG_PATH_TABLE) return fail(MG_EINVAL, "unknown kernel_path");
   if (c.env_id_base < 0 || (uint64_t)c.env_id_base + (uint64_t)c.n_envs > 0xFFFFFFFFull)
     return fail(MG_EINVAL, "global env ids must fit 32 bits");
@@ -845,6 +845,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   h->use_table = false; h->n_entries = 0; h->view_table = nullptr; h->cell_index = nullptr;
   h->stride = (c.n_envs + 63) / 64 * 64;
   h->n_chunks = h->stride / 64;
+  h->dd_bytes = (c.n_agents + 1 <= 4) ? 4 : 8;
   h->PW = c.width + 2 * (c.view_size - 1);
   h->PH = c.height + 2 * (c.view_size - 1);
   h->gx = h->gy = 13;
@@ -866,28 +867,14 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   int rc = MG_OK;
   if (rc == MG_OK) rc = dalloc(h, &h->map_pad, (size_t)h->PW * h->PH);
   if (rc == MG_OK) rc = dalloc(h, &h->dist_lut, (size_t)c.width * c.height);
-  if (rc == MG_OK) rc = dalloc(h, &h->reward_lut, (size_t)c.max_steps + 1);
   if (rc == MG_OK) rc = dalloc(h, &h->cell_index, (size_t)c.width * c.height);
   if (rc == MG_OK) rc = dalloc(h, &h->view_table, (size_t)c.width * c.height * 4 * (var->entw ? var->entw : 4));
   if (rc == MG_OK) rc = dalloc(h, &h->err, 1);
   if (rc == MG_OK) rc = dalloc(h, &h->buf.obs_image, A * S * rowb);
-  if (rc == MG_OK) rc = dalloc(h, &h->buf.obs_dir, A * S);
   if (rc == MG_OK) rc = dalloc(h, &h->buf.reward, A * S);
   if (rc == MG_OK && c.emit_env_reward) rc = dalloc(h, &h->buf.env_reward, A * S);
-  if (rc == MG_OK) rc = dalloc(h, &h->buf.done, S);
+  if (rc == MG_OK) rc = dalloc(h, &h->buf.dir_done, S * (size_t)h->dd_bytes);
   if (rc == MG_OK) rc = dalloc(h, &h->buf.env_state, (A + 1) * S);
-  if (rc == MG_OK) {
-    // MiniGridEnv._reward() for every step count, computed with the host's float64 ops so that
-    // the device returns exactly what CPython computes (multigrid.py:883)
-    std::vector<double> lut((size_t)c.max_steps + 1);
-    for (int s = 0; s <= c.max_steps; ++s) {
-      volatile double q = (double)s / (double)c.max_steps;
-      volatile double m = 0.9 * q;
-      lut[(size_t)s] = 1.0 - m;
-    }
-    e = hipMemcpy(h->reward_lut, lut.data(), lut.size() * sizeof(double), hipMemcpyHostToDevice);
-    if (e != hipSuccess) rc = fail(MG_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
-  }
   if (rc != MG_OK) {
     for (void* q : h->allocs) (void)hipFree(q);
     (void)hipStreamDestroy(h->stream);
@@ -895,6 +882,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
     return rc;
   }
   h->buf.n_envs = c.n_envs; h->buf.env_stride = h->stride; h->buf.n_agents = c.n_agents; h->buf.obs_cell_bytes = rowb;
+  h->buf.dir_done_bytes = h->dd_bytes;
   *out = h;
   return MG_OK;
 }
@@ -1087,6 +1075,25 @@ int mg_get_launch_info(mg_handle* h, int32_t* path, int32_t* block_threads, int3
   if (block_threads) *block_threads = nw * kWave;
   if (grid_blocks) *grid_blocks = (int32_t)grid;
   if (lds_bytes) *lds_bytes = (int32_t)lds;
+  return MG_OK;
+}
+
+__global__ void reward_probe(int max_steps, double* out) {
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s <= max_steps; s += gridDim.x * blockDim.x)
+    out[s] = device_reward((uint32_t)s, max_steps);
+}
+
+// Test hook: the reward formula as the device evaluates it.
+int mg_debug_device_rewards(int device, int32_t max_steps, double* out) {
+  if (!out || max_steps < 1) return fail(MG_EINVAL, "bad argument");
+  DeviceGuard g(device);
+  if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
+  double* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, ((size_t)max_steps + 1) * 8));
+  hipLaunchKernelGGL(reward_probe, dim3(64), dim3(256), 0, 0, (int)max_steps, d);
+  hipError_t e = hipMemcpy(out, d, ((size_t)max_steps + 1) * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(MG_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
   return MG_OK;
 }
 

@@ -7,7 +7,6 @@ LIB_PATH = os.path.join(_HERE, 'libmgrid.so')
 
 MG_OK = 0
 SHAPING_NONE, SHAPING_V8 = 0, 1
-ACT_U8, ACT_I32, ACT_I64 = 1, 4, 8
 PATH_AUTO, PATH_GENERIC, PATH_TABLE = 0, 1, 2
 ERR_BAD_ACTION, ERR_BAD_RESPAWN, ERR_BAD_ORDER, ERR_MISSING_DRAW = 1, 2, 4, 8
 
@@ -16,7 +15,7 @@ class MgConfig(C.Structure):
   _fields_ = [
       ('width', C.c_int32), ('height', C.c_int32), ('n_agents', C.c_int32), ('view_size', C.c_int32),
       ('max_steps', C.c_int32), ('see_through_walls', C.c_int32), ('competitive', C.c_int32),
-      ('shaping_kind', C.c_int32), ('auto_reset', C.c_int32), ('action_dtype', C.c_int32),
+      ('shaping_kind', C.c_int32), ('auto_reset', C.c_int32), ('reserved0', C.c_int32),
       ('emit_env_reward', C.c_int32), ('kernel_path', C.c_int32),
       ('n_envs', C.c_int64), ('env_id_base', C.c_int64), ('seed', C.c_uint64),
   ]
@@ -25,8 +24,8 @@ class MgConfig(C.Structure):
 class MgBuffers(C.Structure):
   _fields_ = [
       ('n_envs', C.c_int64), ('env_stride', C.c_int64), ('n_agents', C.c_int32), ('obs_cell_bytes', C.c_int32),
-      ('obs_image', C.c_void_p), ('obs_dir', C.c_void_p), ('reward', C.c_void_p), ('env_reward', C.c_void_p),
-      ('done', C.c_void_p), ('env_state', C.c_void_p),
+      ('obs_image', C.c_void_p), ('reward', C.c_void_p), ('env_reward', C.c_void_p), ('dir_done', C.c_void_p),
+      ('dir_done_bytes', C.c_int32), ('reserved', C.c_int32), ('env_state', C.c_void_p),
   ]
 
 
@@ -49,6 +48,7 @@ SYMBOLS = {
     'mg_check_errors': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     'mg_get_goal': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'mg_get_launch_info': (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 4),
+    'mg_debug_device_rewards': (C.c_int, [C.c_int, C.c_int32, C.c_void_p]),
     'mg_debug_vis_masks': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     'mg_last_error': (C.c_char_p, []),
     'mg_version': (C.c_char_p, []),

@@ -48,11 +48,11 @@ def test_version_and_error_text_without_gpu():
   assert b'gfx950' in L.mg_version()
   h = C.c_void_p()
   assert L.mg_create(None, 0, C.byref(h)) == -1 and b'null' in L.mg_last_error()
-  cfg = lib.MgConfig(width=2, height=15, n_agents=3, view_size=5, max_steps=100, n_envs=4, action_dtype=1)
+  cfg = lib.MgConfig(width=2, height=15, n_agents=3, view_size=5, max_steps=100, n_envs=4)
   assert L.mg_create(C.byref(cfg), 0, C.byref(h)) == -1 and b'width/height' in L.mg_last_error()
-  cfg = lib.MgConfig(width=15, height=15, n_agents=3, view_size=5, max_steps=100, n_envs=0, action_dtype=1)
+  cfg = lib.MgConfig(width=15, height=15, n_agents=3, view_size=5, max_steps=100, n_envs=0)
   assert L.mg_create(C.byref(cfg), 0, C.byref(h)) == -1
-  cfg = lib.MgConfig(width=15, height=15, n_agents=7, view_size=5, max_steps=100, n_envs=4, action_dtype=1)
+  cfg = lib.MgConfig(width=15, height=15, n_agents=7, view_size=5, max_steps=100, n_envs=4)
   assert L.mg_create(C.byref(cfg), 0, C.byref(h)) == -4      # MG_EUNSUPPORTED: no such instantiation
   assert L.mg_step(None, None) == -1
   assert L.mg_destroy(None) == 0

@@ -174,12 +174,12 @@ def test_on_device_random_actions_parity(cluttered_cells):
   env, orc = _make(cluttered_cells, n, seed=1234, env_id_base=5000)
   env.reset()
   orc.reset()
-  acts = torch.zeros((3, env.stride), dtype=torch.uint8, device=env.device)
+  acts = torch.zeros((env.stride, 4), dtype=torch.uint8, device=env.device)
   oacts = np.zeros((3, orc.stride), np.uint8)
   for t in range(150):
     env.step_random(acts)
     orc.step(None, actions_out=oacts)
-    assert np.array_equal(acts.cpu().numpy()[:, :n], oacts[:, :n])
+    assert np.array_equal(acts.cpu().numpy()[:n, :3].T, oacts[:, :n])
     _cmp_step(env, orc, 'random step %d' % t)
   assert env.check_errors() == 0
 
@@ -224,14 +224,29 @@ def test_error_reporting(cluttered_cells):
   from multigrid_amd import lib
   env, _ = _make(cluttered_cells, 64, seed=2)
   env.reset()
-  bad = torch.full((3, env.stride), 9, dtype=torch.uint8, device=env.device)
+  bad = torch.full((env.stride, 4), 9, dtype=torch.uint8, device=env.device)
   env.step(bad)
   assert env.check_errors() & lib.ERR_BAD_ACTION
   assert env.check_errors() == 0
   # spawn on a wall cell (0,0)
-  sp = torch.zeros((3, env.stride, 4), dtype=torch.int8, device=env.device)
+  sp = torch.zeros((env.stride, 3, 4), dtype=torch.int8, device=env.device)
   env.reset(spawn=sp)
   assert env.check_errors() & lib.ERR_BAD_RESPAWN
+
+
+def test_device_reward_values():
+  """MiniGridEnv._reward() as the device evaluates it (f64 division + multiply + subtract, no
+  contraction) == CPython's value, bit for bit, for every step count of several max_steps —
+  including 100, whose values the reference's own log pins (tests/test_oracle_pins.py)."""
+  _need_gpu()
+  import ctypes as C
+  from multigrid_amd import lib
+  L = lib.load()
+  for max_steps in (100, 250, 640, 2560, 65534):
+    out = np.zeros(max_steps + 1, np.float64)
+    lib.check(L.mg_debug_device_rewards(0, max_steps, out.ctypes.data_as(C.c_void_p)))
+    want = np.array([1 - 0.9 * (s / max_steps) for s in range(max_steps + 1)], np.float64)
+    assert np.array_equal(out.view(np.int64), want.view(np.int64)), max_steps
 
 
 def test_refcompat_env_contract():

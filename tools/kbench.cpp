@@ -51,13 +51,13 @@ int main(int argc, char** argv) {
     SYM(a, check, "mg_check_errors") SYM(a, last_error, "mg_last_error")
     mg_config c{};
     c.width = c.height = 15; c.n_agents = 3; c.view_size = 5; c.max_steps = 100; c.shaping_kind = MG_SHAPING_V8;
-    c.auto_reset = 1; c.action_dtype = MG_ACT_U8; c.n_envs = n; c.seed = 0xC0FFEE;
+    c.auto_reset = 1; c.n_envs = n; c.seed = 0xC0FFEE;
     c.kernel_path = getenv("MG_PATH") ? atoi(getenv("MG_PATH")) : 0;
     if (a.create(&c, 0, &a.h) != MG_OK) { fprintf(stderr, "create: %s\n", a.last_error()); return 1; }
     if (a.set_map(a.h, cells.data()) != MG_OK) { fprintf(stderr, "map: %s\n", a.last_error()); return 1; }
     mg_buffers b;
     a.get_buffers(a.h, &b);
-    const size_t sz = (size_t)3 * b.env_stride;
+    const size_t sz = (size_t)4 * b.env_stride;
     std::vector<uint8_t> host(sz * R);
     uint64_t s = 88172645463325252ull + i;
     for (auto& v : host) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (uint8_t)((s >> 33) % 7); }
@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
   for (int r = 0; r < rounds; ++r)
     for (auto& a : apis) {
       mg_buffers b; a.get_buffers(a.h, &b);
-      const size_t sz = (size_t)3 * b.env_stride;
+      const size_t sz = (size_t)4 * b.env_stride;
       hipEventRecord(e0, a.stream);
       for (int k = 0; k < steps; ++k) a.step(a.h, a.ring + (size_t)(k % R) * sz);
       hipEventRecord(e1, a.stream);
