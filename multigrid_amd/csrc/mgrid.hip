@@ -332,7 +332,10 @@ __device__ __forceinline__ uint32_t asm_load_u32(const void* ptr) {
   return v;
 }
 
-template <int A>
+// FAST = the hot configuration, known at compile time: a free-running step() whose actions come
+// from HBM (no replay injection, no on-device action draw, no env_reward output).  Everything
+// else (reset, replay, step_random, emit_env_reward) runs the general instantiation.
+template <int A, bool FAST>
 __device__ __forceinline__ void load_chunk(const Params& p, int64_t env0, int lane, ChunkIn& in) {
   const int64_t n = env0 + lane;
   in.q = u32x4{0, 0, 0, 0};
@@ -346,7 +349,7 @@ __device__ __forceinline__ void load_chunk(const Params& p, int64_t env0, int la
 #pragma unroll
     for (int a = 0; a <= A; ++a) in.w[a] = asm_load_u32(p.env_state + n * (A + 1) + a);
   }
-  if (p.op == OP_STEP && !p.random_actions) in.act = asm_load_u32(p.actions + n);
+  if (FAST || (p.op == OP_STEP && !p.random_actions)) in.act = asm_load_u32(p.actions + n);
 }
 
 // Retire the loads of load_chunk: at most K vector-memory operations younger than them may stay
@@ -361,7 +364,7 @@ __device__ __forceinline__ void wait_chunk(ChunkIn& in) {
 }
 
 // One chunk (64 envs) of one step()/reset().
-template <int A, int V, bool TAB>
+template <int A, int V, bool TAB, bool FAST>
 __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, const double* dist, const uint32_t* table,
                                          const uint16_t* cidx, uint32_t* stage, int lane, int64_t env0,
                                          const ChunkIn& in, uint32_t& err_acc) {
@@ -391,9 +394,12 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
   }
   uint32_t done_flag = 0;
 
-  if (p.op == OP_STEP) {
+  const bool is_step = FAST || p.op == OP_STEP;
+  const uint32_t* const inj_respawn = FAST ? nullptr : p.respawn;
+  const uint32_t* const inj_spawn = FAST ? nullptr : p.reset_spawn;
+  if (is_step) {
     // ---- actions -------------------------------------------------------------------------
-    if (p.random_actions) {
+    if (!FAST && p.random_actions) {
       const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), (uint32_t)P_ACTION << 28, p.seed_lo, p.seed_hi);
       const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
       actw = 0;
@@ -415,7 +421,7 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
     uint32_t ordw = 0;
 #pragma unroll
     for (int k = 0; k < A; ++k) ordw |= (uint32_t)k << (2 * k);
-    if (p.order) {
+    if (!FAST && p.order) {
       uint32_t seen = 0, w = 0;
       const uint32_t ow = p.order[n];
 #pragma unroll
@@ -426,7 +432,7 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
       }
       if (seen != (1u << A) - 1u) { if (active) err |= MG_ERR_BAD_ORDER; }
       else ordw = w;
-    } else if (A > 1) {
+    } else if (A > 1 && MG_ABL != 3) {
       const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), (uint32_t)P_ORDER << 28, p.seed_lo, p.seed_hi);
       const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
       // Fisher-Yates from the top, as np.random.shuffle does: swap slots i and j = rand(i+1)
@@ -461,7 +467,7 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
       if (go && (cell & F_KILL)) {                                            // goal or lava: agent_is_done :815-832
         dbits |= 1u << a;
         if (cell & F_GOAL) gbits |= 1u << a;                                  // cell re-read is still the goal :881-883
-        const uint32_t w = place_agent<A>(p, map, pd, ((1u << A) - 1u) & ~(1u << a), a, P_RESPAWN, p.respawn, n, gid);
+        const uint32_t w = place_agent<A>(p, map, pd, ((1u << A) - 1u) & ~(1u << a), a, P_RESPAWN, inj_respawn, n, gid);
         npd = w & AW_POSDIR;
         err |= w >> 16;
       }
@@ -481,7 +487,7 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
     for (int a = 0; a < A; ++a) {
       rew[a] = ((gbits >> a) & 1u) ? rgoal : 0.0;
       out_rew[a] = rew[a];
-      if (p.shaping == MG_SHAPING_V8) {
+      if (p.shaping == MG_SHAPING_V8 && MG_ABL != 4) {
         const uint32_t w = shw[a], me = pd_get(pd, a), act = (actw >> (3 * a)) & 7u;
         const int x = aw_x(me), y = aw_y(me);
         uint32_t nw = 0;                              // goal touch: prev_* cleared, count 0 (v8:181-186)
@@ -520,19 +526,19 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
       for (int a = 0; a < A; ++a) {
         const int64_t i = (int64_t)a * p.stride + n;
         p.reward[i] = out_rew[a];
-        if (p.env_reward) p.env_reward[i] = rew[a];
+        if (!FAST && p.env_reward) p.env_reward[i] = rew[a];
       }
     }
   }
 
   // ---- reset() (multigrid.py:466-501; cluttered.py:55-63): the explicit call, or the auto-reset
   //      of an env whose step just returned done (same launch) --------------------------------
-  const bool do_reset = (p.op == OP_RESET) ? (p.mask ? (p.mask[active ? n : 0] != 0) : true)
-                                           : (done_flag && p.auto_reset);
+  const bool do_reset = (!is_step) ? (p.mask ? (p.mask[active ? n : 0] != 0) : true)
+                                   : (done_flag && p.auto_reset);
   if (do_reset) {
 #pragma unroll 1
     for (int a = 0; a < A; ++a) {
-      const uint32_t w = place_agent<A>(p, map, pd, (1u << a) - 1u, a, P_SPAWN, p.reset_spawn, n, gid);
+      const uint32_t w = place_agent<A>(p, map, pd, (1u << a) - 1u, a, P_SPAWN, inj_spawn, n, gid);
       pd = pd_set(pd, a, w & AW_POSDIR);
       err |= w >> 16;
     }
@@ -574,7 +580,7 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
 #endif
 }
 
-template <int A, int V, bool TAB>
+template <int A, int V, bool TAB, bool FAST>
 __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
   constexpr int ROWB = ViewGeom<V>::ROWB, ENTW = ViewGeom<V>::ENTW;
   extern __shared__ __align__(16) uint8_t smem[];
@@ -592,7 +598,7 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
   const int64_t cstride = (int64_t)gridDim.x * nw;
   int64_t c = (int64_t)blockIdx.x * nw + wv;
   ChunkIn cur, nxt;
-  if (c < p.n_chunks) load_chunk<A>(p, c * kWave, lane, cur);
+  if (c < p.n_chunks) load_chunk<A, FAST>(p, c * kWave, lane, cur);
 
   if (TAB) {
     const uint4* src = reinterpret_cast<const uint4*>(p.view_table);
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
   // Vector-memory operations an iteration issues AFTER its prefetch, every one of them for at
   // least one lane of the wave (each chunk has an active lane): obs stores, then env_state and
   // dir_done, and in a step the A reward stores.  A lower bound is all wait_chunk needs.
-#if MG_ABL == 0
+#if MG_ABL == 0 || MG_ABL >= 3
   constexpr int kObs = A * ((4 * ROWB + kWave - 1) / kWave);
 #else
   constexpr int kObs = 0;
@@ -619,10 +625,10 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
   for (; c < p.n_chunks; c += cstride) {
     const int64_t cn = c + cstride;
     const bool more = cn < p.n_chunks;          // wave-uniform
-    if (more) load_chunk<A>(p, cn * kWave, lane, nxt);
-    do_chunk<A, V, TAB>(p, map, dist, table, cidx, stage, lane, c * kWave, cur, err);
+    if (more) load_chunk<A, FAST>(p, cn * kWave, lane, nxt);
+    do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, c * kWave, cur, err);
     if (more) {
-      if (p.op == OP_STEP) wait_chunk<kStep>(nxt); else wait_chunk<kReset>(nxt);
+      if (FAST || p.op == OP_STEP) wait_chunk<kStep>(nxt); else wait_chunk<kReset>(nxt);
       cur = nxt;
     }
   }
@@ -645,16 +651,14 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 typedef void (*kernel_fn)(const Params);
 
-struct Variant { int A, V; kernel_fn generic, table; int entw; };
+// [0] general / [1] FAST instantiation of the generic-path and table-path kernels
+struct Variant { int A, V; kernel_fn generic[2], table[2]; int entw; };
+#define MG_VARIANT_TAB(A, V) {A, V, {mg_kernel<A, V, false, false>, mg_kernel<A, V, false, true>}, \
+                              {mg_kernel<A, V, true, false>, mg_kernel<A, V, true, true>}, ViewGeom<V>::ENTW}
+#define MG_VARIANT_GEN(A, V) {A, V, {mg_kernel<A, V, false, false>, mg_kernel<A, V, false, true>}, {nullptr, nullptr}, 0}
 const Variant kVariants[] = {
-    {1, 5, mg_kernel<1, 5, false>, mg_kernel<1, 5, true>, ViewGeom<5>::ENTW},
-    {2, 5, mg_kernel<2, 5, false>, mg_kernel<2, 5, true>, ViewGeom<5>::ENTW},
-    {3, 5, mg_kernel<3, 5, false>, mg_kernel<3, 5, true>, ViewGeom<5>::ENTW},
-    {4, 5, mg_kernel<4, 5, false>, mg_kernel<4, 5, true>, ViewGeom<5>::ENTW},
-    {3, 3, mg_kernel<3, 3, false>, mg_kernel<3, 3, true>, ViewGeom<3>::ENTW},
-    {1, 7, mg_kernel<1, 7, false>, nullptr, 0},
-    {2, 7, mg_kernel<2, 7, false>, nullptr, 0},
-    {3, 7, mg_kernel<3, 7, false>, nullptr, 0},
+    MG_VARIANT_TAB(1, 5), MG_VARIANT_TAB(2, 5), MG_VARIANT_TAB(3, 5), MG_VARIANT_TAB(4, 5), MG_VARIANT_TAB(3, 3),
+    MG_VARIANT_GEN(1, 7), MG_VARIANT_GEN(2, 7), MG_VARIANT_GEN(3, 7),
 };
 
 // Host twin of static_view<V>: the static view of (x, y, dir) as a table entry
@@ -805,7 +809,8 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   launch_geometry(h, h->use_table, &nw, &grid, &lds);
   DeviceGuard g(h->device);
   if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
-  hipLaunchKernelGGL(h->use_table ? h->var->table : h->var->generic, dim3(grid), dim3(nw * kWave), lds, h->stream, p);
+  const int fast = (op == OP_STEP && !order && !respawn && !reset_spawn && !random_actions && !h->buf.env_reward) ? 1 : 0;
+  hipLaunchKernelGGL(h->use_table ? h->var->table[fast] : h->var->generic[fast], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
   HIP_TRY(hipGetLastError());
   return MG_OK;
 }
@@ -832,7 +837,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   for (const Variant& v : kVariants)
     if (v.A == c.n_agents && v.V == c.view_size) var = &v;
   if (!var) return fail(MG_EUNSUPPORTED, "no kernel instantiated for this (n_agents, view_size)");
-  if (c.kernel_path == MG_PATH_TABLE && !var->table) return fail(MG_EUNSUPPORTED, "no table kernel for this view_size");
+  if (c.kernel_path == MG_PATH_TABLE && !var->table[0]) return fail(MG_EUNSUPPORTED, "no table kernel for this view_size");
 
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
@@ -856,7 +861,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   h->own_stream = true;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail(MG_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
-  for (kernel_fn fn : {var->generic, var->table}) {
+  for (kernel_fn fn : {var->generic[0], var->generic[1], var->table[0], var->table[1]}) {
     if (!fn) continue;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
     if (e != hipSuccess) { (void)hipStreamDestroy(h->stream); delete h; return fail(MG_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
@@ -937,7 +942,7 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
   // part is a pure function of (cell, dir)).
   const Variant* var = h->var;
   std::vector<uint32_t> table;
-  bool use_table = var->table != nullptr && cfg.kernel_path != MG_PATH_GENERIC;
+  bool use_table = var->table[0] != nullptr && cfg.kernel_path != MG_PATH_GENERIC;
   if (use_table) {
     h->n_entries = n_free * 4;
     table.assign((size_t)h->n_entries * var->entw, 0u);

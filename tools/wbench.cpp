@@ -39,6 +39,47 @@ __global__ __launch_bounds__(1024) void k_pattern(uint8_t* obs, double* rew, uin
   }
 }
 
+// the v4 kernel's exact streams, inputs prefetched one iteration ahead (asm loads, counted vmcnt):
+// state uint4 RMW, actions dword read, dir_done dword, 3 f64 rewards, 3 obs chunks
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_pattern4(uint8_t* obs, double* rew, uint4* state, uint32_t* dd,
+                                                   const uint32_t* act, int64_t stride_envs, int64_t n_chunks) {
+  typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int64_t cs = (int64_t)gridDim.x * nw;
+  int64_t c = (int64_t)blockIdx.x * nw + wv;
+  v4 cur, nxt; uint32_t ca, na;
+  if (c < n_chunks) {
+    const void* p0 = state + c * 64 + lane; const void* p1 = act + c * 64 + lane;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(cur) : "v"(p0) : "memory");
+    asm volatile("global_load_dword %0, %1, off" : "=&v"(ca) : "v"(p1) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur), "+v"(ca) :: "memory");
+  }
+  for (; c < n_chunks; c += cs) {
+    const int64_t n = c * 64 + lane;
+    const bool more = c + cs < n_chunks;
+    if (more) {
+      const void* p0 = state + (c + cs) * 64 + lane; const void* p1 = act + (c + cs) * 64 + lane;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(nxt) : "v"(p0) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "=&v"(na) : "v"(p1) : "memory");
+    }
+    v4 st = cur; st.x += ca;
+    if (MODE == 0) {
+      for (int a = 0; a < 3; ++a) rew[a * stride_envs + n] = (double)st.x;
+      dd[n] = st.y;
+    } else if (MODE == 1) {   // [S][32 B] record: 3 f64 rewards + dir_done
+      v4* r = reinterpret_cast<v4*>(rew) + n * 2;
+      r[0] = st; r[1] = st;
+    }
+    *reinterpret_cast<v4*>(state + n) = st;
+    for (int a = 0; a < 3; ++a) {
+      v4* dst = reinterpret_cast<v4*>(obs + (a * stride_envs + c * 64) * 75);
+      for (int i = 0; i < 5; ++i) { const int idx = i * 64 + lane; if (idx < 300) dst[idx] = st; }
+    }
+    if (more) { asm volatile("s_waitcnt vmcnt(16)" : "+v"(nxt), "+v"(na) :: "memory"); cur = nxt; ca = na; }
+  }
+}
+
 int main(int argc, char** argv) {
   const int64_t n = argc > 1 ? atoll(argv[1]) : 4194304;
   const int nw = argc > 2 ? atoi(argv[2]) : 16;
@@ -67,5 +108,11 @@ int main(int argc, char** argv) {
       {"pattern: obs only nt", 33, 225.0}};
   for (auto& pt : pats)
     timeit(pt.name, n * pt.bytes, [&] { hipLaunchKernelGGL(k_pattern, dim3(grid), dim3(nw * 64), 0, 0, obs, rew, state, dir, done, act, n, n / 64, pt.mode); });
+  uint32_t* dd; hipMalloc((void**)&dd, n * 4);
+  uint32_t* act4; hipMalloc((void**)&act4, n * 4); hipMemset(act4, 1, n * 4);
+  hipFree(rew); hipMalloc((void**)&rew, n * 32);
+  timeit("pattern4: v4 streams, prefetched inputs", n * 289.0, [&] { hipLaunchKernelGGL(k_pattern4<0>, dim3(grid), dim3(nw * 64), 0, 0, obs, rew, state, dd, act4, n, n / 64); });
+  timeit("pattern4: reward+dir_done as one 32-B record", n * 293.0, [&] { hipLaunchKernelGGL(k_pattern4<1>, dim3(grid), dim3(nw * 64), 0, 0, obs, rew, state, dd, act4, n, n / 64); });
+  timeit("pattern4: obs + state RMW + act only", n * 261.0, [&] { hipLaunchKernelGGL(k_pattern4<3>, dim3(grid), dim3(nw * 64), 0, 0, obs, rew, state, dd, act4, n, n / 64); });
   return 0;
 }
