@@ -66,6 +66,16 @@ def cpu_baseline(cells, seconds=12.0):
   return out
 
 
+def measured_traffic(envs):
+  """HBM bytes per launch from the committed PMC passes (profiles/r1_traffic.json), when they were
+  taken at this batch size; None otherwise (counters cannot be read from inside the bench)."""
+  try:
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')))
+    return d['hbm_bytes_per_launch'] if d['envs_per_gpu'] == envs else None
+  except Exception:
+    return None
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -138,8 +148,8 @@ def main():
                                'uniform random actions resident in HBM' % (ENV_ID, n),
                    'envs_per_gpu': n, 'global_envs': n * world, 'parallelism': 'env-sharded x%d, no collective in step' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                     'kernel': 'mg_kernel<3,5>', 'kernel_ms': kernel_ms,
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(n),
+                     'kernel': 'mg_kernel<3,5,table,fast>', 'kernel_ms': kernel_ms, 'launch': env.launch_info(),
                      'alg_bytes_per_launch': B_ALG_PER_ENV_STEP * n},
         'device_errors': errs,
     }
