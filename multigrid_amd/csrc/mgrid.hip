@@ -40,6 +40,7 @@ constexpr int kWave = 64;
 constexpr int kMaxBlock = 1024;
 constexpr int kMaxAttempts = 256;    // rejection-sampling cap, then a deterministic scan
 constexpr int kLdsLimit = 160 * 1024;
+constexpr int kUpfront = 4;         // chunks per wave whose inputs are all fetched before the first store
 enum { P_ORDER = 0, P_RESPAWN = 1, P_SPAWN = 2, P_ACTION = 3 };
 enum { OP_STEP = 0, OP_RESET = 1 };
 
@@ -621,15 +622,32 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
   constexpr int kObs = 0;
 #endif
   constexpr int kStep = (kObs + 2 + A) < 63 ? (kObs + 2 + A) : 63, kReset = (kObs + 2) < 63 ? (kObs + 2) : 63;
-  if (c < p.n_chunks) wait_chunk<0>(cur);
-  for (; c < p.n_chunks; c += cstride) {
-    const int64_t cn = c + cstride;
-    const bool more = cn < p.n_chunks;          // wave-uniform
-    if (more) load_chunk<A, FAST>(p, cn * kWave, lane, nxt);
-    do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, c * kWave, cur, err);
-    if (more) {
-      if (FAST || p.op == OP_STEP) wait_chunk<kStep>(nxt); else wait_chunk<kReset>(nxt);
-      cur = nxt;
+  if (FAST && p.n_chunks <= cstride * kUpfront) {
+    // Launch-resident batch (at most kUpfront chunks per wave): fetch ALL inputs first, then only
+    // store.  The whole chip then runs one read burst followed by an uninterrupted write stream,
+    // which the memory system serves faster than reads interleaved with writes.
+    ChunkIn in[kUpfront];
+    in[0] = cur;
+#pragma unroll
+    for (int k = 1; k < kUpfront; ++k)
+      if (c + k * cstride < p.n_chunks) load_chunk<A, FAST>(p, (c + k * cstride) * kWave, lane, in[k]);
+#pragma unroll
+    for (int k = 0; k < kUpfront; ++k) wait_chunk<0>(in[k]);
+#pragma unroll
+    for (int k = 0; k < kUpfront; ++k)
+      if (c + k * cstride < p.n_chunks)
+        do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, (c + k * cstride) * kWave, in[k], err);
+  } else {
+    if (c < p.n_chunks) wait_chunk<0>(cur);
+    for (; c < p.n_chunks; c += cstride) {
+      const int64_t cn = c + cstride;
+      const bool more = cn < p.n_chunks;          // wave-uniform
+      if (more) load_chunk<A, FAST>(p, cn * kWave, lane, nxt);
+      do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, c * kWave, cur, err);
+      if (more) {
+        if (FAST || p.op == OP_STEP) wait_chunk<kStep>(nxt); else wait_chunk<kReset>(nxt);
+        cur = nxt;
+      }
     }
   }
   if (err) atomicOr(p.err, err);
@@ -781,6 +799,8 @@ void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid
   const int64_t blocks = (h->n_chunks + nw - 1) / nw;
   *nw_out = nw;
   *grid_out = (unsigned)std::min<int64_t>(blocks, (int64_t)h->n_cu * per_cu);
+  if (const char* e = getenv("MG_DEBUG_GRID"))   // tests only: few workgroups => many chunks per wave
+    *grid_out = (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, atoi(e)));
   *lds_out = lds;
 }
 
@@ -942,7 +962,10 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
   // part is a pure function of (cell, dir)).
   const Variant* var = h->var;
   std::vector<uint32_t> table;
-  bool use_table = var->table[0] != nullptr && cfg.kernel_path != MG_PATH_GENERIC;
+  // AUTO: the table costs ~3 us of LDS fill per workgroup, which only pays off from ~64K envs
+  // (measured: 32768 envs 10.4 us generic vs 11.0 us table; 131072 envs 14.7 vs 12.5)
+  bool use_table = var->table[0] != nullptr && cfg.kernel_path != MG_PATH_GENERIC &&
+                   (cfg.kernel_path == MG_PATH_TABLE || h->n_chunks >= 1024);
   if (use_table) {
     h->n_entries = n_free * 4;
     table.assign((size_t)h->n_entries * var->entw, 0u);

@@ -60,6 +60,7 @@ def lib():
     L.mgo_process_vis.argtypes = [C.c_int, u8p, u8p]
     L.mgo_process_vis_bits.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
     L.mgo_philox.argtypes = [C.POINTER(C.c_uint32)] * 3
+    L.mgo_batch_state.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     L.mgo_batch_reset.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, i8p, C.c_uint64, u8p, u8p]
     L.mgo_batch_step.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, u8p, i8p, i8p,
                                  C.c_uint64, u8p, u8p, f64p, f64p, u8p, u8p]
@@ -233,12 +234,14 @@ class OracleBatch:
                           _p(self.env_reward, f64p), _p(self.done, u8p), _p(actions_out, u8p))
     self.t += 1
 
+  def _states(self):
+    ag = np.zeros((self.A, self.stride), np.uint32)
+    st = np.zeros(self.stride, np.uint32)
+    self.L.mgo_batch_state(self.envs, self.n, self.stride, ag.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p))
+    return ag, st
+
   def agent_state(self):
-    out = np.zeros((self.A, self.stride), np.uint32)
-    for i in range(self.n):
-      for a in range(self.A):
-        out[a, i] = self.L.mgo_agent_state(self.envs[i], a)
-    return out
+    return self._states()[0]
 
   def shaper_state(self):
     out = np.zeros((self.A, self.stride), np.uint32)
@@ -248,10 +251,7 @@ class OracleBatch:
     return out
 
   def step_state(self):
-    out = np.zeros(self.stride, np.uint32)
-    for i in range(self.n):
-      out[i] = self.L.mgo_step_state(self.envs[i])
-    return out
+    return self._states()[1]
 
   def last_draws(self):
     """(order uint8[A,stride], respawn int8[A,stride,4], spawn int8[A,stride,4]) of the last call."""

@@ -588,6 +588,15 @@ void mgo_put_obj(mgo_env* e, int x, int y, int type, int color, int state) {
 }
 void mgo_set_step_count(mgo_env* e, int s) { e->step_count = s; }
 
+void mgo_batch_state(mgo_env** envs, int64_t n, int64_t stride, uint32_t* agent_state /* [A][stride] */,
+                     uint32_t* step_state /* [stride] */) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    for (int a = 0; a < envs[i]->A; ++a) agent_state[(int64_t)a * stride + i] = mgo_agent_state(envs[i], a);
+    step_state[i] = mgo_step_state(envs[i]);
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * Batched drivers over the product's agent-major layouts (include/mgrid.h), so tests can
  * compare device arrays with oracle arrays element for element.  stride = env_stride.

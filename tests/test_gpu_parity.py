@@ -88,6 +88,36 @@ def test_free_running_philox_parity(cluttered_cells, n, steps, seed):
     assert touches > 0   # the rare branch (goal touch + respawn) was exercised
 
 
+@pytest.mark.parametrize('path,n,grid,nw', [('table', 3000, None, None),      # all inputs fetched up front
+                                            ('table', 20000, 3, 4),          # rolling prefetch, 26 chunks per wave
+                                            ('generic', 20000, 2, 4), ('table', 70000, None, None)])
+def test_fast_instantiation_parity(cluttered_cells, monkeypatch, path, n, grid, nw):
+  """The FAST instantiation (free-running step, actions from HBM, no env_reward output — the one
+  bench.py times) against the oracle, on both of its chunk loops: launch-resident batches fetch
+  every input before the first store; larger ones prefetch one chunk ahead behind a counted
+  s_waitcnt.  MG_DEBUG_GRID / MG_DEBUG_NW shrink the grid so that a small batch takes the
+  many-chunks-per-wave loop."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  if grid is not None:
+    monkeypatch.setenv('MG_DEBUG_GRID', str(grid))
+    monkeypatch.setenv('MG_DEBUG_NW', str(nw))
+  env = BatchedMultiGrid(cluttered_cells, n_envs=n, seed=77, kernel_path=path)    # no env_reward => FAST
+  orc = c_oracle.OracleBatch(cluttered_cells, n, shaping=1, auto_reset=1, seed=77)
+  rng = np.random.RandomState(77)
+  env.reset()
+  orc.reset()
+  for t in range(105):
+    act = rng.randint(0, 7, size=(3, orc.stride)).astype(np.uint8)
+    act[rng.rand(3, orc.stride) < 0.35] = 2
+    env.step(torch.from_numpy(act).to(env.device))
+    orc.step(act)
+    if t % 8 == 0 or t >= 98:
+      _cmp_step(env, orc, 'fast %s step %d' % (path, t))
+  _cmp_step(env, orc, 'fast %s final' % path)
+  assert env.check_errors() == 0
+
+
 @pytest.mark.parametrize('path', ['generic', 'table'])
 def test_forced_kernel_paths_parity(cluttered_cells, path):
   """Both ways of producing the static view (per-step slice/rotate/process_vis from the LDS map,
@@ -322,3 +352,27 @@ def test_full_size_properties():
   own = a.obs_image[:, :, 2, 4, :].reshape(-1, 3)
   assert bool((own == torch.tensor([1, 0, 0], dtype=torch.uint8, device=a.device)).all().item())
   assert a.check_errors() == 0
+
+
+def test_full_size_fast_vs_general_instantiation():
+  """BASELINE config 3 at 1,048,576 envs on one GPU (the bench.py workload): the FAST instantiation
+  bench.py times must produce exactly what the general instantiation (the one checked against
+  the oracle above) produces from the same actions — across an auto-reset boundary."""
+  _need_gpu()
+  import multigrid_amd
+  n = 1 << 20
+  fast = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', n, seed=9)
+  gen = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', n, seed=9, emit_env_reward=True)
+  assert fast.launch_info()['path'] == 'table'
+  fast.reset(); gen.reset()
+  g = torch.Generator(device=fast.device)
+  g.manual_seed(4)
+  for t in range(104):
+    act = torch.randint(0, 7, (fast.stride, 4), dtype=torch.uint8, device=fast.device, generator=g)
+    fast.step(act); gen.step(act)
+    if t in (0, 50, 99, 100, 103):
+      assert torch.equal(fast.obs_image, gen.obs_image), t
+      assert torch.equal(fast.reward, gen.reward) and torch.equal(fast._dir_done, gen._dir_done), t
+      assert torch.equal(fast.env_state, gen.env_state), t
+  assert bool(fast.done.all().item()) is False and int(fast.step_count.max().item()) == 4
+  assert fast.check_errors() == 0 and gen.check_errors() == 0

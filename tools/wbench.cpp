@@ -80,6 +80,37 @@ __global__ __launch_bounds__(1024) void k_pattern4(uint8_t* obs, double* rew, ui
   }
 }
 
+// inputs fetched in groups of G chunks per wave (one read burst), then G chunks of stores
+template <int G>
+__global__ __launch_bounds__(1024) void k_pattern_grouped(uint8_t* obs, double* rew, uint4* state, uint32_t* dd,
+                                                          const uint32_t* act, int64_t stride_envs, int64_t n_chunks) {
+  typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int64_t cs = (int64_t)gridDim.x * nw;
+  for (int64_t c0 = (int64_t)blockIdx.x * nw + wv; c0 < n_chunks; c0 += cs * G) {
+    v4 st[G]; uint32_t ca[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int64_t c = c0 + g * cs;
+      if (c < n_chunks) { st[g] = *reinterpret_cast<const v4*>(state + c * 64 + lane); ca[g] = act[c * 64 + lane]; }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int64_t c = c0 + g * cs;
+      if (c >= n_chunks) break;
+      const int64_t n = c * 64 + lane;
+      v4 s = st[g]; s.x += ca[g];
+      for (int a = 0; a < 3; ++a) rew[a * stride_envs + n] = (double)s.x;
+      dd[n] = s.y;
+      *reinterpret_cast<v4*>(state + n) = s;
+      for (int a = 0; a < 3; ++a) {
+        v4* dst = reinterpret_cast<v4*>(obs + (a * stride_envs + c * 64) * 75);
+        for (int i = 0; i < 5; ++i) { const int idx = i * 64 + lane; if (idx < 300) dst[idx] = s; }
+      }
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const int64_t n = argc > 1 ? atoll(argv[1]) : 4194304;
   const int nw = argc > 2 ? atoi(argv[2]) : 16;
@@ -114,5 +145,7 @@ int main(int argc, char** argv) {
   timeit("pattern4: v4 streams, prefetched inputs", n * 289.0, [&] { hipLaunchKernelGGL(k_pattern4<0>, dim3(grid), dim3(nw * 64), 0, 0, obs, rew, state, dd, act4, n, n / 64); });
   timeit("pattern4: reward+dir_done as one 32-B record", n * 293.0, [&] { hipLaunchKernelGGL(k_pattern4<1>, dim3(grid), dim3(nw * 64), 0, 0, obs, rew, state, dd, act4, n, n / 64); });
   timeit("pattern4: obs + state RMW + act only", n * 261.0, [&] { hipLaunchKernelGGL(k_pattern4<3>, dim3(grid), dim3(nw * 64), 0, 0, obs, rew, state, dd, act4, n, n / 64); });
+  timeit("grouped reads G=4", n * 289.0, [&] { hipLaunchKernelGGL(k_pattern_grouped<4>, dim3(grid), dim3(nw * 64), 0, 0, obs, rew, state, dd, act4, n, n / 64); });
+  timeit("grouped reads G=8", n * 289.0, [&] { hipLaunchKernelGGL(k_pattern_grouped<8>, dim3(grid), dim3(nw * 64), 0, 0, obs, rew, state, dd, act4, n, n / 64); });
   return 0;
 }
