@@ -83,6 +83,8 @@ def main():
   ap.add_argument('--warmup', type=int, default=200)
   ap.add_argument('--envs', type=int, default=1 << 20, help='envs per GPU (weak scaling)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N>1 (nccl = RCCL); gloo only to rehearse on one GPU')
+  ap.add_argument('--all-on-device0', action='store_true', help='rehearsal: every rank uses cuda:0')
   ap.add_argument('--cpu-seconds', type=float, default=12.0)
   args = ap.parse_args()
 
@@ -94,10 +96,15 @@ def main():
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   dist = None
-  if world > 1:
+  if args.all_on_device0:
+    local_rank = 0
+  if world > 1 or 'RANK' in os.environ:
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if args.backend == 'nccl':
+      dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+      dist.init_process_group(args.backend)
   else:
     torch.cuda.set_device(0)
     local_rank = 0
