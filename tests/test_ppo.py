@@ -1,0 +1,203 @@
+"""the batched v8 policy / GAE / PPO update against literal restatements of the
+reference's per-sample code (v8_robust_ppo.py:35-102, 275-345).  Pure PyTorch, runs on CPU; the
+env stand-in is the C oracle behind the BatchedMultiGrid tensor interface."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+import torch.nn.functional as F  # noqa: E402
+
+from multigrid_amd import ppo  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _literal_forward(sd, image_xyc, direction):
+  """SimplePPOAgent.forward for ONE observation, written out op by op (v8:69-95):
+  image [5,5,3] -> permute(2,0,1).unsqueeze(0) -> conv/relu x2 -> global average -> cat embed -> MLP."""
+  x = image_xyc.permute(2, 0, 1).unsqueeze(0).float()
+  x = F.relu(F.conv2d(x, sd['image_conv.0.weight'], sd['image_conv.0.bias'], padding=1))
+  x = F.relu(F.conv2d(x, sd['image_conv.2.weight'], sd['image_conv.2.bias'], padding=1))
+  x = x.mean(dim=(2, 3))
+  e = sd['direction_embed.weight'][int(direction)].unsqueeze(0)
+  h = torch.cat([x, e], dim=-1)
+  h = F.relu(F.linear(h, sd['shared.0.weight'], sd['shared.0.bias']))
+  h = F.relu(F.linear(h, sd['shared.2.weight'], sd['shared.2.bias']))
+  return F.linear(h, sd['actor.weight'], sd['actor.bias'])[0], F.linear(h, sd['critic.weight'], sd['critic.bias'])[0, 0]
+
+
+def test_agent_net_matches_reference_architecture():
+  torch.manual_seed(0)
+  net = ppo.AgentNet()
+  sd = net.state_dict()
+  # the reference's parameter names and shapes (v8:38-61), so its .pth checkpoints load as they are
+  want = {'image_conv.0.weight': (32, 3, 3, 3), 'image_conv.0.bias': (32,), 'image_conv.2.weight': (64, 32, 3, 3),
+          'image_conv.2.bias': (64,), 'direction_embed.weight': (4, 8), 'shared.0.weight': (128, 72),
+          'shared.0.bias': (128,), 'shared.2.weight': (64, 128), 'shared.2.bias': (64,), 'actor.weight': (7, 64),
+          'actor.bias': (7,), 'critic.weight': (1, 64), 'critic.bias': (1,)}
+  assert {k: tuple(v.shape) for k, v in sd.items()} == want
+  assert sum(v.numel() for v in sd.values()) == 37544                       # ~37.5 k params
+  assert float(sd['actor.bias'].abs().sum()) == 0.0                           # zero biases (v8:67)
+  w = sd['shared.2.weight']
+  assert torch.allclose(w @ w.t(), 0.25 * torch.eye(64), atol=1e-5)            # orthogonal, gain 0.5 (v8:66)
+  img = torch.randint(0, 11, (9, 5, 5, 3), dtype=torch.uint8)
+  d = torch.randint(0, 4, (9,))
+  logits, values = net(img, d)
+  for i in range(9):
+    l, v = _literal_forward(sd, img[i], d[i])
+    assert torch.allclose(logits[i], l, atol=1e-6) and torch.allclose(values[i], v, atol=1e-6)
+
+
+def _literal_gae(rewards, values, dones, gamma=0.99, lam=0.95):
+  """compute_gae (v8:275-293) on Python lists."""
+  adv, ret, a = [], [], 0
+  for t in reversed(range(len(rewards))):
+    nv = 0 if t == len(rewards) - 1 else values[t + 1]
+    nt = 1 - dones[t]
+    delta = rewards[t] + gamma * nv * nt - values[t]
+    a = delta + gamma * lam * nt * a
+    adv.insert(0, a)
+    ret.insert(0, a + values[t])
+  return adv, ret
+
+
+def test_gae_matches_reference_loop():
+  rng = np.random.RandomState(1)
+  T, N = 37, 5
+  r, v = rng.randn(T, N), rng.randn(T, N)
+  dones = np.zeros(T, bool)
+  dones[[11, 36]] = True
+  adv, ret = ppo.compute_gae(torch.tensor(r), torch.tensor(v), torch.tensor(dones))
+  for n in range(N):
+    la, lr = _literal_gae(list(r[:, n]), list(v[:, n]), [float(x) for x in dones])
+    assert np.allclose(adv[:, n].numpy(), la, atol=1e-12) and np.allclose(ret[:, n].numpy(), lr, atol=1e-12)
+
+
+def test_ppo_loss_matches_reference_formula():
+  torch.manual_seed(2)
+  net = ppo.AgentNet()
+  B = 33
+  img = torch.randint(0, 11, (B, 5, 5, 3), dtype=torch.uint8)
+  d = torch.randint(0, 4, (B,))
+  act = torch.randint(0, 7, (B,))
+  old_lp, adv, ret = -torch.rand(B) * 2, torch.randn(B), torch.randn(B)
+  loss = ppo.ppo_loss(net, img, d, act, old_lp, adv, ret)
+  logits, val = net(img, d)
+  lp = torch.log_softmax(logits, -1)
+  new_lp = lp.gather(1, act[:, None])[:, 0]
+  ent = -(lp.exp() * lp).sum(-1)
+  ratio = (new_lp - old_lp).exp()
+  want = -torch.min(ratio * adv, ratio.clamp(0.8, 1.2) * adv).mean() + 0.5 * ((val - ret) ** 2).mean() - 0.02 * ent.mean()
+  assert torch.allclose(loss, want, atol=1e-6)
+
+
+class OracleEnvTensors:
+  """The C oracle behind BatchedMultiGrid's tensor interface (CPU stand-in for the device env)."""
+
+  def __init__(self, n, seed=0, gid_base=0):
+    from multigrid_amd import layouts
+    from oracle import c_oracle
+    self.o = c_oracle.OracleBatch(layouts.cluttered_fixed_15x15(), n, shaping=1, auto_reset=1, seed=seed, gid_base=gid_base)
+    self.n_envs, self.n_agents, self.stride = n, 3, self.o.stride
+    self.actions = torch.full((self.stride, 4), 6, dtype=torch.uint8)
+    self.o.reset()
+    self._sync()
+
+  def _sync(self):
+    n = self.n_envs
+    self.obs_image = torch.from_numpy(self.o.obs_image[:, :n].reshape(3, n, 5, 5, 3).copy())
+    self.obs_dir = torch.from_numpy(self.o.obs_dir[:, :n].copy())
+    self.reward = torch.from_numpy(self.o.reward[:, :n].copy())
+    self.done = torch.from_numpy(self.o.done[:n].copy())
+
+  def step(self):
+    self.o.step(np.ascontiguousarray(self.actions.numpy()[:, :3].T))
+    self._sync()
+
+
+def test_rollout_and_update_run_on_the_env_interface():
+  env = OracleEnvTensors(48, seed=3)
+  ctl = ppo.BatchedController(env, device=torch.device('cpu'), ddp=False, seed=5)
+  traj = ctl.rollout(101)
+  assert traj['image'][0].shape == (101, 48, 5, 5, 3) and traj['done'].shape == (101, 48)
+  assert bool(traj['done'][99].all()) and not bool(traj['done'][:99].any())      # episodes end at step 100
+  assert int(traj['action'][2].max()) <= 6
+  before = [p.detach().clone() for p in ctl.nets[0].parameters()]
+  losses = ctl.update(traj)
+  assert len(losses) == 3 and all(np.isfinite(losses))
+  assert any(not torch.equal(a, b) for a, b in zip(before, ctl.nets[0].parameters()))
+
+
+def _ddp_worker(rank, world, port, out_dir):
+  sys.path.insert(0, ROOT)
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  import torch.distributed as dist
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  from multigrid_amd import ppo as P, shard
+  from test_ppo import OracleEnvTensors
+  base, n = shard.shard_range(rank, world, 16)
+  env = OracleEnvTensors(n, seed=3, gid_base=base)          # different envs per rank
+  ctl = P.BatchedController(env, device=torch.device('cpu'), seed=5)
+  assert ctl.ddp
+  torch.manual_seed(100 + rank)                             # different action samples per rank
+  ctl.update(ctl.rollout(40))
+  torch.save([p.detach() for p in ctl.nets[1].parameters()], os.path.join(out_dir, 'p%d.pt' % rank))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_ddp_gradient_allreduce_keeps_ranks_in_lockstep(tmp_path):
+  import torch.multiprocessing as mp
+  port = 29700 + (os.getpid() % 1500)
+  mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  p0 = torch.load(os.path.join(str(tmp_path), 'p0.pt'), weights_only=True)
+  p1 = torch.load(os.path.join(str(tmp_path), 'p1.pt'), weights_only=True)
+  assert all(torch.equal(a, b) for a, b in zip(p0, p1))     # same weights after 4 all-reduced epochs
+
+
+def test_multigrid_net_matches_reference_layout():
+  torch.manual_seed(1)
+  net = ppo.MultiGridNet(n_actions=7, n_agents=3)
+  sd = net.state_dict()
+  assert tuple(sd['image_layers.0.weight'].shape) == (32, 3, 3, 3) and tuple(sd['image_layers.5.weight'].shape) == (64, 64)
+  assert tuple(sd['direction_layers.0.weight'].shape) == (8, 12) and tuple(sd['head.0.weight'].shape) == (192, 72)
+  img = torch.randint(0, 11, (4, 5, 5, 3), dtype=torch.uint8)
+  dirs = torch.randint(0, 4, (4, 3))
+  q = net(img, dirs)
+  # literal forward for sample 2 (multigrid_network.py:57-79)
+  x = img[2:3].permute(0, 3, 1, 2).float()
+  x = F.leaky_relu(F.conv2d(x, sd['image_layers.0.weight'], sd['image_layers.0.bias']))
+  x = F.leaky_relu(F.conv2d(x, sd['image_layers.2.weight'], sd['image_layers.2.bias'])).reshape(1, -1)
+  x = F.leaky_relu(F.linear(x, sd['image_layers.5.weight'], sd['image_layers.5.bias']))
+  oh = F.one_hot(dirs[2:3], 4).reshape(1, -1).float()
+  e = F.relu(F.linear(oh, sd['direction_layers.0.weight'], sd['direction_layers.0.bias']))
+  h = torch.cat([x, e], -1)
+  h = F.relu(F.linear(h, sd['head.0.weight'], sd['head.0.bias']))
+  h = F.relu(F.linear(h, sd['head.2.weight'], sd['head.2.bias']))
+  want = F.linear(h, sd['head.4.weight'], sd['head.4.bias'])
+  assert q.shape == (4, 7) and torch.allclose(q[2:3], want, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_rollout_update_on_device_env():
+  """Config 5 shape on one GPU: HIP env + three batched nets, zero-copy obs, no host sync per step."""
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  import multigrid_amd
+  env = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', 2048, seed=1)
+  env.reset()
+  ctl = ppo.BatchedController(env, ddp=False, seed=2)
+  traj = ctl.rollout(100)
+  assert traj['image'][0].is_cuda and traj['image'][0].shape == (100, 2048, 5, 5, 3)
+  assert bool(traj['done'][99].all().item()) and not bool(traj['done'][:99].any().item())
+  assert int(torch.stack(traj['action']).max().item()) <= 6
+  losses = ctl.update(traj)
+  assert all(np.isfinite(losses)) and env.check_errors() == 0
+  # the stored observation of step t is what the env held before step t: re-derive step 0's obs
+  env2 = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', 2048, seed=1)
+  env2.reset()
+  assert torch.equal(traj['image'][1][0], env2.obs_image[1])

@@ -1,0 +1,46 @@
+"""End-to-end v8 PPO throughput on the device env (BASELINE config 5):
+rollout (3 batched policy forwards + one env kernel per step) and update (GAE + 4 epochs).
+    python tools/bench_ppo.py --envs 16384 --steps 100 --iters 3
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--envs', type=int, default=16384)
+  ap.add_argument('--steps', type=int, default=100)
+  ap.add_argument('--iters', type=int, default=3)
+  args = ap.parse_args()
+  import torch
+  import multigrid_amd
+  from multigrid_amd import ppo
+  env = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', args.envs, seed=0)
+  env.reset()
+  ctl = ppo.BatchedController(env, ddp=False)
+  ctl.update(ctl.rollout(args.steps))            # warm-up (MIOpen/hipBLASLt heuristics)
+  torch.cuda.synchronize()
+  tr = tu = 0.0
+  for _ in range(args.iters):
+    t0 = time.perf_counter()
+    traj = ctl.rollout(args.steps)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    ctl.update(traj)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    tr += t1 - t0
+    tu += t2 - t1
+  n = args.envs * 3 * args.steps * args.iters
+  print(json.dumps({'envs': args.envs, 'steps': args.steps, 'rollout_agent_steps_per_s': n / tr,
+                    'end_to_end_agent_steps_per_s': n / (tr + tu), 'rollout_s': tr / args.iters, 'update_s': tu / args.iters,
+                    'reference_v8_end_to_end_agent_steps_per_s': 1.6e3}))
+
+
+if __name__ == '__main__':
+  main()
