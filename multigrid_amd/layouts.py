@@ -63,3 +63,28 @@ def cluttered(size=15, n_clutter=25, randomize_goal=True, walls_are_lava=False, 
 def cluttered_fixed_15x15():
   """ClutteredMultiGridFixed15x15 (cluttered.py:47-52): 30 walls, goal (13,13), seed 52."""
   return cluttered(size=15, n_clutter=30, randomize_goal=False, seed=52)
+
+
+def object_playground():
+  """A 9x9 test map holding every object type the mutable-grid step handles (keys, balls, a box,
+  doors in all three states, a floor tile, lava, goal).  Not a reference env: a synthetic map for
+  parity tests of pickup / drop / toggle / overlap on a fixed base layout."""
+  KEY, BALL, BOX, DOOR, FLOOR = 5, 6, 7, 4, 3
+  BLUE, PURPLE, YELLOW = 2, 3, 4
+  g = empty_bordered(9, 9, goal=(7, 7))
+  g[4, 1:4] = (WALL, GREY, 0)
+  g[4, 5:8] = (WALL, GREY, 0)
+  g[4, 4] = (DOOR, YELLOW, 2)     # locked, opened by the yellow key
+  g[2, 4] = (DOOR, RED, 1)        # closed, unlocked
+  g[6, 4] = (DOOR, BLUE, 0)       # open: walking through destroys it (move_agent overwrites the cell)
+  g[1, 1] = (KEY, YELLOW, 0)
+  g[3, 6] = (KEY, RED, 0)
+  g[2, 2] = (BALL, BLUE, 0)
+  g[5, 2] = (BALL, PURPLE, 0)
+  g[1, 6] = (BOX, GREEN, 0)
+  g[6, 6] = (BOX, YELLOW, 0)
+  g[3, 2] = (FLOOR, BLUE, 0)
+  g[7, 1] = (LAVA, RED, 0)
+  g[5, 7] = (LAVA, RED, 0)
+  g[1, 7] = (GOAL, GREEN, 0)      # a second goal: get_goal_position takes the first in x-major order
+  return g

@@ -64,8 +64,32 @@ def lib():
     L.mgo_batch_reset.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, i8p, C.c_uint64, u8p, u8p]
     L.mgo_batch_step.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, u8p, i8p, i8p,
                                  C.c_uint64, u8p, u8p, f64p, f64p, u8p, u8p]
+    L.mgo_set_kind.argtypes = [C.c_void_p, C.c_int]
+    L.mgo_reset_gen.argtypes = [C.c_void_p, i8p, i8p, C.c_uint64]
+    L.mgo_step_ex.argtypes = [C.c_void_p, i32p, u8p, i8p, i8p, i8p, i8p, C.c_uint64, u8p, u8p, f64p, f64p, u8p]
+    L.mgo_carry_word.restype = C.c_uint32
+    L.mgo_carry_word.argtypes = [C.c_void_p]
+    L.mgo_grid_kinds.argtypes = [C.c_void_p, u8p]
+    L.mgo_last_gen.argtypes = [C.c_void_p, i8p, i8p]
+    L.mgo_batch_reset_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, i8p, i8p, C.c_uint64, u8p, u8p]
+    L.mgo_batch_step_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, u8p, i8p, i8p, i8p, i8p,
+                                    C.c_uint64, u8p, u8p, f64p, f64p, u8p, u8p]
+    L.mgo_batch_dyn_state.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_void_p, u8p]
     _LIB = L
   return _LIB
+
+
+KIND_STATIC, KIND_DOORKEY = 0, 1
+KINDS = {'static': KIND_STATIC, 'doorkey': KIND_DOORKEY}
+
+
+def kind_id(type_, color=0, state=0):
+  """One-byte cell kind of the product's per-env grids (mg_oracle.c kind_of)."""
+  if type_ in (0, 1, 10):
+    return 0
+  if type_ == 4:
+    return 128 + color * 4 + state
+  return type_ * 8 + color
 
 
 def _p(arr, typ):
@@ -104,14 +128,16 @@ class OracleEnv:
   """One oracle env with the reference's (obs, rewards, done, info) call shape."""
 
   def __init__(self, cells, W=15, H=15, A=3, V=5, max_steps=100, see_through=0, competitive=0,
-               shaping=0, auto_reset=0, seed=0, gid=0):
+               shaping=0, auto_reset=0, seed=0, gid=0, kind='static'):
     self.L = lib()
     self.W, self.H, self.A, self.V = W, H, A, V
     self.h = self.L.mgo_create(W, H, A, V, max_steps, see_through, competitive, shaping, auto_reset, seed, gid)
     if not self.h:
       raise ValueError('bad oracle config')
-    cells = np.ascontiguousarray(cells, dtype=np.uint8).reshape(W * H * 3)
-    self.L.mgo_set_map(self.h, _p(cells, u8p))
+    self.L.mgo_set_kind(self.h, KINDS[kind])
+    if cells is not None:
+      cells = np.ascontiguousarray(cells, dtype=np.uint8).reshape(W * H * 3)
+      self.L.mgo_set_map(self.h, _p(cells, u8p))
     self.t = 0
 
   def __del__(self):
@@ -125,18 +151,23 @@ class OracleEnv:
     self.L.mgo_get_obs(self.h, _p(img, u8p), _p(d, u8p))
     return {'image': [img[a] for a in range(self.A)], 'direction': [int(x) for x in d]}
 
-  def reset(self, spawn=None):
+  def reset(self, spawn=None, gen=None):
     sp = None
     if spawn is not None:
       sp = np.zeros((self.A, 4), np.int8)
       sp[:, :3] = np.asarray(spawn, np.int8)
-    self.L.mgo_reset(self.h, _p(sp, i8p), self.t)
+    g = None if gen is None else np.asarray(gen, np.int8).reshape(4)
+    self.L.mgo_reset_gen(self.h, _p(sp, i8p), _p(g, i8p), self.t)
     return self._obs()
 
-  def step(self, actions, order=None, respawn=None, reset_spawn=None):
+  def step(self, actions, order=None, respawn=None, reset_spawn=None, objdrop=None, reset_gen=None):
     act = np.asarray(actions, np.int32)
     od = None if order is None else np.asarray(order, np.uint8)
-    rs = sp = None
+    rs = sp = ob = None
+    if objdrop is not None:
+      ob = np.zeros((self.A, 4), np.int8)
+      ob[:, :2] = np.asarray(objdrop, np.int8)[:, :2]
+    rg = None if reset_gen is None else np.asarray(reset_gen, np.int8).reshape(4)
     if respawn is not None:
       rs = np.zeros((self.A, 4), np.int8)
       rs[:, :3] = np.asarray(respawn, np.int8)
@@ -148,8 +179,8 @@ class OracleEnv:
     rw = np.zeros(self.A, np.float64)
     er = np.zeros(self.A, np.float64)
     dn = np.zeros(1, np.uint8)
-    self.L.mgo_step(self.h, _p(act, i32p), _p(od, u8p), _p(rs, i8p), _p(sp, i8p), self.t,
-                    _p(img, u8p), _p(d, u8p), _p(rw, f64p), _p(er, f64p), _p(dn, u8p))
+    self.L.mgo_step_ex(self.h, _p(act, i32p), _p(od, u8p), _p(rs, i8p), _p(ob, i8p), _p(sp, i8p), _p(rg, i8p),
+                       self.t, _p(img, u8p), _p(d, u8p), _p(rw, f64p), _p(er, f64p), _p(dn, u8p))
     self.t += 1
     self.env_rewards = er
     obs = {'image': [img[a] for a in range(self.A)], 'direction': [int(x) for x in d]}
@@ -186,22 +217,47 @@ class OracleEnv:
   def set_step_count(self, s):
     self.L.mgo_set_step_count(self.h, s)
 
+  def carry_word(self):
+    return self.L.mgo_carry_word(self.h)
+
+  def grid_kinds(self):
+    g = np.zeros((self.H, self.W), np.uint8)
+    self.L.mgo_grid_kinds(self.h, _p(g, u8p))
+    return g
+
+  def last_gen(self):
+    """((split, door, key_x, key_y), objdrop int8[A,4]) recorded by the last reset / step."""
+    g = np.zeros(4, np.int8)
+    o = np.zeros((self.A, 4), np.int8)
+    self.L.mgo_last_gen(self.h, _p(g, i8p), _p(o, i8p))
+    return g, o
+
+  def last_draws(self):
+    o = np.zeros(self.A, np.uint8)
+    r = np.zeros((self.A, 4), np.int8)
+    s = np.zeros((self.A, 4), np.int8)
+    self.L.mgo_last_draws(self.h, _p(o, u8p), _p(r, i8p), _p(s, i8p))
+    return o, r, s
+
 
 class OracleBatch:
   """n oracle envs over the product's buffer layouts."""
 
   def __init__(self, cells, n, W=15, H=15, A=3, V=5, max_steps=100, see_through=0, competitive=0,
-               shaping=0, auto_reset=0, seed=0, gid_base=0):
+               shaping=0, auto_reset=0, seed=0, gid_base=0, kind='static'):
     self.L = lib()
     self.n, self.A, self.V, self.W, self.H = n, A, V, W, H
     self.stride = (n + 63) // 64 * 64
-    cells = np.ascontiguousarray(cells, dtype=np.uint8).reshape(W * H * 3)
+    if cells is not None:
+      cells = np.ascontiguousarray(cells, dtype=np.uint8).reshape(W * H * 3)
     self.envs = (C.c_void_p * n)()
     for i in range(n):
       h = self.L.mgo_create(W, H, A, V, max_steps, see_through, competitive, shaping, auto_reset, seed, gid_base + i)
       if not h:
         raise ValueError('bad oracle config')
-      self.L.mgo_set_map(h, _p(cells, u8p))
+      self.L.mgo_set_kind(h, KINDS[kind])
+      if cells is not None:
+        self.L.mgo_set_map(h, _p(cells, u8p))
       self.envs[i] = h
     cb = V * V * 3
     s = self.stride
@@ -218,21 +274,47 @@ class OracleBatch:
         self.L.mgo_destroy(self.envs[i])
         self.envs[i] = None
 
-  def reset(self, mask=None, spawn=None):
+  def reset(self, mask=None, spawn=None, gen=None):
+    """spawn int8[A,stride,4]; gen int8[stride,4] = (split, door, key_x, key_y) (DoorKey replay)."""
     m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
     sp = None if spawn is None else np.ascontiguousarray(spawn, np.int8)
-    self.L.mgo_batch_reset(self.envs, self.n, self.stride, _p(m, u8p), _p(sp, i8p), self.t,
-                           _p(self.obs_image, u8p), _p(self.obs_dir, u8p))
+    g = None if gen is None else np.ascontiguousarray(gen, np.int8)
+    self.L.mgo_batch_reset_ex(self.envs, self.n, self.stride, _p(m, u8p), _p(sp, i8p), _p(g, i8p), self.t,
+                              _p(self.obs_image, u8p), _p(self.obs_dir, u8p))
 
-  def step(self, actions=None, order=None, respawn=None, reset_spawn=None, actions_out=None):
+  def step(self, actions=None, order=None, respawn=None, reset_spawn=None, actions_out=None, objdrop=None,
+           reset_gen=None):
     a = None if actions is None else np.ascontiguousarray(actions, np.uint8)
     o = None if order is None else np.ascontiguousarray(order, np.uint8)
     r = None if respawn is None else np.ascontiguousarray(respawn, np.int8)
     s = None if reset_spawn is None else np.ascontiguousarray(reset_spawn, np.int8)
-    self.L.mgo_batch_step(self.envs, self.n, self.stride, _p(a, u8p), _p(o, u8p), _p(r, i8p), _p(s, i8p),
-                          self.t, _p(self.obs_image, u8p), _p(self.obs_dir, u8p), _p(self.reward, f64p),
-                          _p(self.env_reward, f64p), _p(self.done, u8p), _p(actions_out, u8p))
+    ob = None if objdrop is None else np.ascontiguousarray(objdrop, np.int8)
+    rg = None if reset_gen is None else np.ascontiguousarray(reset_gen, np.int8)
+    self.L.mgo_batch_step_ex(self.envs, self.n, self.stride, _p(a, u8p), _p(o, u8p), _p(r, i8p), _p(ob, i8p),
+                             _p(s, i8p), _p(rg, i8p), self.t, _p(self.obs_image, u8p), _p(self.obs_dir, u8p),
+                             _p(self.reward, f64p), _p(self.env_reward, f64p), _p(self.done, u8p),
+                             _p(actions_out, u8p))
     self.t += 1
+
+  def dyn_state(self):
+    """(carry uint32[stride], kinds uint8[stride, H, W]) of the mutable-grid state."""
+    carry = np.zeros(self.stride, np.uint32)
+    kinds = np.zeros((self.stride, self.H, self.W), np.uint8)
+    self.L.mgo_batch_dyn_state(self.envs, self.n, self.stride, carry.ctypes.data_as(C.c_void_p), _p(kinds, u8p))
+    return carry, kinds
+
+  def last_gen(self):
+    """(gen int8[stride,4], objdrop int8[A,stride,4]) recorded by the last reset / step."""
+    gen = np.zeros((self.stride, 4), np.int8)
+    objdrop = np.full((self.A, self.stride, 4), -1, np.int8)
+    objdrop[:, :, 2:] = 0
+    g = np.zeros(4, np.int8)
+    o = np.zeros((self.A, 4), np.int8)
+    for i in range(self.n):
+      self.L.mgo_last_gen(self.envs[i], _p(g, i8p), _p(o, i8p))
+      gen[i] = g
+      objdrop[:, i] = o
+    return gen, objdrop
 
   def _states(self):
     ag = np.zeros((self.A, self.stride), np.uint32)

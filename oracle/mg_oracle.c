@@ -85,7 +85,8 @@ static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
 }
 void mgo_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
 
-enum { P_ORDER = 0, P_RESPAWN = 1, P_SPAWN = 2, P_ACTION = 3 };
+enum { P_ORDER = 0, P_RESPAWN = 1, P_SPAWN = 2, P_ACTION = 3, P_GEN = 4, P_KEY = 5, P_OBJDROP = 6 };
+enum { KIND_STATIC = 0, KIND_DOORKEY = 1 };
 #define MAX_ATTEMPTS 256
 
 static uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
@@ -108,6 +109,12 @@ typedef struct mgo_env {
   /* recorder: what the last step drew, in the layout replay mode injects */
   uint8_t last_order[MAXA];
   int8_t last_respawn[MAXA * 4], last_spawn[MAXA * 4];
+  /* procedurally generated kinds (DoorKey): */
+  int kind;                    /* KIND_* */
+  int spawn_w;                 /* agents are (re)placed at x < spawn_w (doorkey.py:69-86); W otherwise */
+  const int8_t* inj_gen;       /* injected (split_idx, door_idx, key_x, key_y) or NULL */
+  const int8_t* inj_obj;       /* injected (x, y, 0, 0) per agent for a carried object re-placed on death, or NULL */
+  int8_t last_gen[4], last_objdrop[MAXA * 4];
 } mgo_env;
 
 mgo_env* mgo_create(int W, int H, int A, int V, int max_steps, int see_through, int competitive,
@@ -118,8 +125,10 @@ mgo_env* mgo_create(int W, int H, int A, int V, int max_steps, int see_through, 
   e->competitive = (A == 1) ? 1 : competitive;      /* multigrid.py:380-381 */
   e->shaping = shaping; e->auto_reset = auto_reset; e->seed = seed; e->gid = gid;
   e->base.w = e->grid.w = W; e->base.h = e->grid.h = H;
+  e->kind = KIND_STATIC; e->spawn_w = W;
   return e;
 }
+void mgo_set_kind(mgo_env* e, int kind) { e->kind = kind; }
 void mgo_destroy(mgo_env* e) { free(e); }
 
 /* cells: uint8[W*H*3], [(y*W+x)*3+c]; type 1 (empty) and 0 mean None */
@@ -135,12 +144,27 @@ void mgo_set_map(mgo_env* e, const uint8_t* cells) {
 
 /* ---- placement: place_obj / place_one_agent / place_agent_at_pos (multigrid.py:560-675) ---- */
 
-static void draw_candidate(mgo_env* e, int agent, int attempt, int* x, int* y, int* dir) {
+static void draw_words(const mgo_env* e, int purpose, int agent, int attempt, uint32_t r[4]) {
   uint32_t ctr[4] = {(uint32_t)e->gid, (uint32_t)e->t, (uint32_t)(e->t >> 32),
-                     ((uint32_t)e->purpose << 28) | ((uint32_t)agent << 20) | (uint32_t)attempt};
-  uint32_t key[2] = {(uint32_t)e->seed, (uint32_t)(e->seed >> 32)}, r[4];
+                     ((uint32_t)purpose << 28) | ((uint32_t)agent << 20) | (uint32_t)attempt};
+  uint32_t key[2] = {(uint32_t)e->seed, (uint32_t)(e->seed >> 32)};
   philox4x32_10(ctr, key, r);
-  *x = (int)mulhi32(r[0], (uint32_t)e->W);   /* _rand_int(0, grid.width)  multigrid.py:598-599 */
+}
+
+/* one candidate of place_obj's loop: x in [0, min(size_w, W)), y in [0, H) (multigrid.py:598-601;
+ * top = (0,0), size = (xmax, height) — doorkey.py:56,64-65,77-78) */
+static void draw_candidate_in(mgo_env* e, int purpose, int agent, int attempt, int xmax, int* x, int* y, int* dir) {
+  uint32_t r[4];
+  draw_words(e, purpose, agent, attempt, r);
+  *x = (int)mulhi32(r[0], (uint32_t)(xmax < e->W ? xmax : e->W));
+  *y = (int)mulhi32(r[1], (uint32_t)e->H);
+  *dir = (int)(r[2] >> 30);
+}
+
+static void draw_candidate(mgo_env* e, int agent, int attempt, int* x, int* y, int* dir) {
+  uint32_t r[4];
+  draw_words(e, e->purpose, agent, attempt, r);
+  *x = (int)mulhi32(r[0], (uint32_t)(e->spawn_w < e->W ? e->spawn_w : e->W));   /* _rand_int(0, min(size_w, grid.width)) multigrid.py:598-599 */
   *y = (int)mulhi32(r[1], (uint32_t)e->H);   /* _rand_int(0, grid.height) multigrid.py:600-601 */
   *dir = (int)(r[2] >> 30);                  /* _rand_int(0, 4)           multigrid.py:666 */
 }
@@ -163,7 +187,7 @@ static void place_one_agent(mgo_env* e, int a) {
     const int8_t* p = e->inj + 4 * a;
     x = p[0]; y = p[1]; dir = p[2];
     if (x < 0) { e->err |= ERR_MISSING_DRAW; x = -1; }
-    else if (!cell_free(e, x, y) || dir < 0 || dir > 3) { e->err |= ERR_BAD_RESPAWN; x = -1; }
+    else if (!cell_free(e, x, y) || x >= e->spawn_w || dir < 0 || dir > 3) { e->err |= ERR_BAD_RESPAWN; x = -1; }
   } else {
     for (int k = 0; k < MAX_ATTEMPTS; ++k) {           /* while True: multigrid.py:589-619 */
       int cx, cy, cd;
@@ -176,7 +200,7 @@ static void place_one_agent(mgo_env* e, int a) {
      * storage order, direction 0.  (The reference would loop forever, multigrid.py:644.) */
     dir = 0;
     for (int j = 0; j < e->H && x < 0; ++j)
-      for (int i = 0; i < e->W; ++i)
+      for (int i = 0; i < e->W && i < e->spawn_w; ++i)
         if (cell_free(e, i, j)) { x = i; y = j; break; }
     if (x < 0) { x = 0; y = 0; }
   }
@@ -188,6 +212,31 @@ static void place_one_agent(mgo_env* e, int a) {
   e->adir[a] = dir;                                    /* multigrid.py:665-666 */
   obj_t ag = {T_AGENT, (uint8_t)a, (uint8_t)dir, 0};   /* multigrid.py:669-675 */
   grid_set(&e->grid, x, y, ag);
+}
+
+/* place_obj for a non-agent object (multigrid.py:560-627) inside x < xmax: injected position or
+ * Philox rejection sampling with the given purpose; same bounded-loop fallback as agents. */
+static void place_object(mgo_env* e, obj_t obj, int purpose, int agent, int xmax, const int8_t* inj, int8_t* rec) {
+  int x = -1, y = -1, d;
+  if (inj) {
+    x = inj[0]; y = inj[1];
+    if (x < 0) { e->err |= ERR_MISSING_DRAW; x = -1; }
+    else if (!cell_free(e, x, y) || x >= xmax) { e->err |= ERR_BAD_RESPAWN; x = -1; }
+  } else {
+    for (int k = 0; k < MAX_ATTEMPTS; ++k) {
+      int cx, cy;
+      draw_candidate_in(e, purpose, agent, k, xmax, &cx, &cy, &d);
+      if (cell_free(e, cx, cy)) { x = cx; y = cy; break; }
+    }
+  }
+  if (x < 0) {
+    for (int j = 0; j < e->H && x < 0; ++j)
+      for (int i = 0; i < e->W && i < xmax; ++i)
+        if (cell_free(e, i, j)) { x = i; y = j; break; }
+    if (x < 0) { x = 0; y = 0; }
+  }
+  if (rec) { rec[0] = (int8_t)x; rec[1] = (int8_t)y; rec[2] = 0; rec[3] = 0; }
+  grid_set(&e->grid, x, y, obj);
 }
 
 /* ---- observation: gen_obs_grid / slice / rotate_left / process_vis / encode ---- */
@@ -317,17 +366,51 @@ static void clear_shaper(mgo_env* e) {                /* v8_robust_ppo.py:227-22
   for (int a = 0; a < e->A; ++a) { e->sh_has[a] = 0; e->sh_dist[a] = 0.0; e->sh_px[a] = e->sh_py[a] = 0; e->sh_stat[a] = 0; }
 }
 
+/* DoorKeyEnv._gen_grid (multigrid_envs/doorkey.py:34-67).  Draw order of the reference: split_idx,
+ * agents (x < split_idx), door_idx, key (x < split_idx). */
+static void gen_doorkey(mgo_env* e) {
+  const int W = e->W, H = e->H;
+  const obj_t wall = {T_WALL, C_GREY, 0, 0}, goal = {T_GOAL, C_GREEN, 0, 0};
+  for (int j = 0; j < H; ++j)
+    for (int i = 0; i < W; ++i)                          /* Grid(width,height); wall_rect(0,0,w,h) :38-41 */
+      grid_set(&e->grid, i, j, (i == 0 || j == 0 || i == W - 1 || j == H - 1) ? wall : NONE);
+  grid_set(&e->grid, W - 2, H - 2, goal);                /* put_obj(Goal, w-2, h-2) :44 */
+  int split, door;
+  if (e->inj_gen) { split = e->inj_gen[0]; door = e->inj_gen[1]; }
+  else {
+    uint32_t r[4];
+    draw_words(e, P_GEN, 0, 0, r);
+    const int start = W <= 5 ? 2 : 3;                    /* :47-50 */
+    split = start + (int)mulhi32(r[0], (uint32_t)(W - 2 - start));   /* _rand_int(start_idx, width-2) :51 */
+    door = 1 + (int)mulhi32(r[1], (uint32_t)(W - 2 - 1));            /* _rand_int(1, width-2) :59 */
+  }
+  if (split < 1 || split > W - 2 || door < 1 || door > H - 2) { e->err |= ERR_BAD_RESPAWN; split = W <= 5 ? 2 : 3; door = 1; }
+  for (int j = 0; j < H; ++j) grid_set(&e->grid, split, j, wall);    /* vert_wall(split_idx, 0) :52 */
+  e->spawn_w = split;
+  for (int a = 0; a < e->A; ++a) place_one_agent(e, a);  /* place_agent(size=(split_idx,height)) :56 */
+  const obj_t doorobj = {T_DOOR, C_YELLOW, 2, 0}, keyobj = {T_KEY, C_YELLOW, 0, 0};
+  grid_set(&e->grid, split, door, doorobj);              /* put_obj(Door('yellow', is_locked=True)) :60-61 */
+  place_object(e, keyobj, P_KEY, 0, split, e->inj_gen ? e->inj_gen + 2 : NULL, e->last_gen + 2);   /* :64-65 */
+  e->last_gen[0] = (int8_t)split; e->last_gen[1] = (int8_t)door;
+}
+
 static void do_reset(mgo_env* e, const int8_t* spawn, uint64_t t) {
   for (int a = 0; a < e->A; ++a) { e->has_pos[a] = 0; e->done[a] = 0; }   /* multigrid.py:471-473 */
-  e->grid = e->base;                                   /* _gen_grid with the fixed seed */
   e->inj = spawn; e->purpose = P_SPAWN; e->t = t;
-  for (int a = 0; a < e->A; ++a) place_one_agent(e, a); /* cluttered.py:61-63 */
+  if (e->kind == KIND_DOORKEY) gen_doorkey(e);
+  else {
+    e->grid = e->base;                                   /* _gen_grid with the fixed seed */
+    for (int a = 0; a < e->A; ++a) place_one_agent(e, a); /* cluttered.py:61-63 */
+  }
   for (int a = 0; a < e->A; ++a) e->carrying[a] = NONE; /* multigrid.py:490 */
   e->step_count = 0;                                    /* multigrid.py:493 */
   clear_shaper(e);
 }
 
-void mgo_reset(mgo_env* e, const int8_t* spawn /* [A][4] or NULL */, uint64_t t) { do_reset(e, spawn, t); }
+void mgo_reset(mgo_env* e, const int8_t* spawn /* [A][4] or NULL */, uint64_t t) { e->inj_gen = NULL; do_reset(e, spawn, t); }
+void mgo_reset_gen(mgo_env* e, const int8_t* spawn, const int8_t* gen /* [4] or NULL */, uint64_t t) {
+  e->inj_gen = gen; do_reset(e, spawn, t); e->inj_gen = NULL;
+}
 
 void mgo_get_obs(const mgo_env* e, uint8_t* image /* [A][V*V*3] */, uint8_t* dir /* [A] */) {
   for (int a = 0; a < e->A; ++a) gen_agent_obs(e, a, image + a * e->V * e->V * 3, dir + a);
@@ -339,10 +422,10 @@ void mgo_get_obs(const mgo_env* e, uint8_t* image /* [A][V*V*3] */, uint8_t* dir
 static void agent_is_done(mgo_env* e, int a) {
   grid_set(&e->grid, e->ax[a], e->ay[a], NONE);         /* multigrid.py:817-819 */
   e->done[a] = 1;                                       /* multigrid.py:821 */
+  e->last_objdrop[4 * a] = -1; e->last_objdrop[4 * a + 1] = -1;
   if (e->carrying[a].type != T_NONE) {
-    /* multigrid.py:827-829: place_obj(carrying) — needs its own draws; no static-map env can
-     * carry anything, so this branch is unreachable in the current scope. */
-    e->err |= ERR_MISSING_DRAW;
+    /* multigrid.py:827-829: place_obj(carrying) anywhere on the grid, before the agent respawns */
+    place_object(e, e->carrying[a], P_OBJDROP, a, e->W, e->inj_obj ? e->inj_obj + 4 * a : NULL, e->last_objdrop + 4 * a);
     e->carrying[a] = NONE;
   }
   place_one_agent(e, a);                                /* multigrid.py:832 */
@@ -484,10 +567,21 @@ static void shape_rewards(mgo_env* e, const double* orig, const int* actions, do
 /* MultiGridEnv.step (multigrid.py:963-995) followed by the v8 shaper (v8:239-243) and the
  * build's auto-reset.  order == NULL -> Philox Fisher-Yates; respawn/reset_spawn == NULL ->
  * Philox rejection sampling.  t = step index (Philox counter).  Outputs may be NULL. */
+void mgo_step_ex(mgo_env* e, const int* actions, const uint8_t* order, const int8_t* respawn,
+                 const int8_t* objdrop, const int8_t* reset_spawn, const int8_t* reset_gen, uint64_t t,
+                 uint8_t* image, uint8_t* dir, double* reward, double* env_rew, uint8_t* done_out);
 void mgo_step(mgo_env* e, const int* actions, const uint8_t* order, const int8_t* respawn,
               const int8_t* reset_spawn, uint64_t t, uint8_t* image, uint8_t* dir, double* reward,
               double* env_rew, uint8_t* done_out) {
+  mgo_step_ex(e, actions, order, respawn, NULL, reset_spawn, NULL, t, image, dir, reward, env_rew, done_out);
+}
+/* objdrop: injected (x,y,0,0) per agent for the carried object place_obj re-places when that agent
+ * finishes (multigrid.py:827-829); reset_gen: injected DoorKey layout draws for an auto-reset. */
+void mgo_step_ex(mgo_env* e, const int* actions, const uint8_t* order, const int8_t* respawn,
+                 const int8_t* objdrop, const int8_t* reset_spawn, const int8_t* reset_gen, uint64_t t,
+                 uint8_t* image, uint8_t* dir, double* reward, double* env_rew, uint8_t* done_out) {
   int A = e->A, ord[MAXA];
+  e->inj_obj = objdrop;
   e->step_count += 1;                                    /* multigrid.py:968 */
   double rewards[MAXA];
   for (int a = 0; a < A; ++a) rewards[a] = 0;            /* multigrid.py:970 */
@@ -510,6 +604,7 @@ void mgo_step(mgo_env* e, const int* actions, const uint8_t* order, const int8_t
   for (int a = 0; a < A; ++a) {
     e->last_order[a] = (uint8_t)ord[a];
     e->last_respawn[4 * a] = -1; e->last_respawn[4 * a + 1] = -1; e->last_respawn[4 * a + 2] = 0; e->last_respawn[4 * a + 3] = 0;
+    e->last_objdrop[4 * a] = -1; e->last_objdrop[4 * a + 1] = -1; e->last_objdrop[4 * a + 2] = 0; e->last_objdrop[4 * a + 3] = 0;
   }
   for (int k = 0; k < A; ++k) {                          /* multigrid.py:977-978 */
     int a = ord[k];
@@ -527,7 +622,8 @@ void mgo_step(mgo_env* e, const int* actions, const uint8_t* order, const int8_t
   if (e->shaping == 1) shape_rewards(e, rewards, actions, shaped);
   else for (int a = 0; a < A; ++a) shaped[a] = rewards[a];
 
-  if (collective_done && e->auto_reset) do_reset(e, reset_spawn, t);
+  if (collective_done && e->auto_reset) { e->inj_gen = reset_gen; do_reset(e, reset_spawn, t); e->inj_gen = NULL; }
+  e->inj_obj = NULL;
 
   if (image && dir) mgo_get_obs(e, image, dir);          /* multigrid.py:980 */
   for (int a = 0; a < A; ++a) {
@@ -563,7 +659,29 @@ uint32_t mgo_shaper_state(const mgo_env* e, int a) {
 uint32_t mgo_step_state(const mgo_env* e) {
   uint32_t d = 0;
   for (int a = 0; a < e->A; ++a) d |= (uint32_t)(e->done[a] != 0) << a;
-  return (uint32_t)e->step_count | (d << 16);
+  uint32_t w = (uint32_t)e->step_count | (d << 16);
+  if (e->kind != KIND_STATIC) w |= (uint32_t)e->spawn_w << 24;   /* dynamic-grid kinds keep the spawn region here */
+  return w;
+}
+/* One-byte cell kind used by the product's per-env grids: 0 = None, door = 128 + color*4 + state,
+ * anything else = type*8 + color (state is 0 for every non-door object). */
+static uint8_t kind_of(obj_t o) {
+  if (o.type == T_NONE || o.type == T_AGENT) return 0;
+  if (o.type == T_DOOR) return (uint8_t)(128 + o.color * 4 + o.state);
+  return (uint8_t)(o.type * 8 + o.color);
+}
+uint32_t mgo_carry_word(const mgo_env* e) {
+  uint32_t w = 0;
+  for (int a = 0; a < e->A && a < 4; ++a) w |= (uint32_t)kind_of(e->carrying[a]) << (8 * a);
+  return w;
+}
+void mgo_grid_kinds(const mgo_env* e, uint8_t* out /* [H*W], index y*W+x; agents' cells read 0 */) {
+  for (int y = 0; y < e->H; ++y)
+    for (int x = 0; x < e->W; ++x) out[y * e->W + x] = kind_of(grid_get(&e->grid, x, y));
+}
+void mgo_last_gen(const mgo_env* e, int8_t* gen /* [4] */, int8_t* objdrop /* [A][4] */) {
+  if (gen) memcpy(gen, e->last_gen, 4);
+  if (objdrop) memcpy(objdrop, e->last_objdrop, (size_t)e->A * 4);
 }
 /* what the last step/reset drew: order[A], respawn[A][4], spawn[A][4] */
 void mgo_last_draws(const mgo_env* e, uint8_t* order, int8_t* respawn, int8_t* spawn) {
@@ -649,5 +767,68 @@ void mgo_batch_step(mgo_env** envs, int64_t n, int64_t stride, const uint8_t* ac
       if (env_rew) env_rew[o] = er[a];
     }
     if (done) done[i] = dn;
+  }
+}
+
+/* dynamic-grid kinds: batched drivers with the extra injection streams (same layouts as the
+ * product: gen int8[stride][4]; objdrop int8[A][stride][4] agent-major like respawn) */
+void mgo_batch_reset_ex(mgo_env** envs, int64_t n, int64_t stride, const uint8_t* mask, const int8_t* spawn,
+                        const int8_t* gen, uint64_t t, uint8_t* image, uint8_t* dir) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    mgo_env* e = envs[i];
+    if (mask && !mask[i]) continue;
+    int8_t sp[MAXA * 4];
+    if (spawn) for (int a = 0; a < e->A; ++a) memcpy(sp + 4 * a, spawn + ((int64_t)a * stride + i) * 4, 4);
+    mgo_reset_gen(e, spawn ? sp : NULL, gen ? gen + i * 4 : NULL, t);
+    if (image && dir) {
+      uint8_t img[MAXA * MAXV * MAXV * 3], d[MAXA];
+      int cb = e->V * e->V * 3;
+      mgo_get_obs(e, img, d);
+      for (int a = 0; a < e->A; ++a) {
+        memcpy(image + ((int64_t)a * stride + i) * cb, img + a * cb, (size_t)cb);
+        dir[(int64_t)a * stride + i] = d[a];
+      }
+    }
+  }
+}
+
+void mgo_batch_step_ex(mgo_env** envs, int64_t n, int64_t stride, const uint8_t* actions, const uint8_t* order,
+                       const int8_t* respawn, const int8_t* objdrop, const int8_t* reset_spawn, const int8_t* reset_gen,
+                       uint64_t t, uint8_t* image, uint8_t* dir, double* reward, double* env_rew, uint8_t* done,
+                       uint8_t* actions_out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    mgo_env* e = envs[i];
+    int A = e->A, act[MAXA], cb = e->V * e->V * 3;
+    uint8_t ord[MAXA]; int8_t rs[MAXA * 4], sp[MAXA * 4], od[MAXA * 4];
+    if (actions) for (int a = 0; a < A; ++a) act[a] = actions[(int64_t)a * stride + i];
+    else mgo_random_actions(e, t, act);
+    if (actions_out) for (int a = 0; a < A; ++a) actions_out[(int64_t)a * stride + i] = (uint8_t)act[a];
+    if (order) for (int k = 0; k < A; ++k) ord[k] = order[(int64_t)k * stride + i];
+    if (respawn) for (int a = 0; a < A; ++a) memcpy(rs + 4 * a, respawn + ((int64_t)a * stride + i) * 4, 4);
+    if (objdrop) for (int a = 0; a < A; ++a) memcpy(od + 4 * a, objdrop + ((int64_t)a * stride + i) * 4, 4);
+    if (reset_spawn) for (int a = 0; a < A; ++a) memcpy(sp + 4 * a, reset_spawn + ((int64_t)a * stride + i) * 4, 4);
+    uint8_t img[MAXA * MAXV * MAXV * 3], d[MAXA], dn;
+    double rw[MAXA], er[MAXA];
+    mgo_step_ex(e, act, order ? ord : NULL, respawn ? rs : NULL, objdrop ? od : NULL, reset_spawn ? sp : NULL,
+                reset_gen ? reset_gen + i * 4 : NULL, t, image ? img : NULL, image ? d : NULL, rw, er, &dn);
+    for (int a = 0; a < A; ++a) {
+      int64_t o = (int64_t)a * stride + i;
+      if (image) { memcpy(image + o * cb, img + a * cb, (size_t)cb); dir[o] = d[a]; }
+      if (reward) reward[o] = rw[a];
+      if (env_rew) env_rew[o] = er[a];
+    }
+    if (done) done[i] = dn;
+  }
+}
+
+void mgo_batch_dyn_state(mgo_env** envs, int64_t n, int64_t stride, uint32_t* carry /* [stride] */,
+                         uint8_t* kinds /* [stride][H*W] */) {
+  (void)stride;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    carry[i] = mgo_carry_word(envs[i]);
+    mgo_grid_kinds(envs[i], kinds + i * envs[i]->W * envs[i]->H);
   }
 }

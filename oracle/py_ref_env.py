@@ -92,6 +92,18 @@ class Ball(Thing):
     super().__init__('ball', color)
 
 
+class Box(Thing):
+  """minigrid Box with no contents: toggle replaces it with its contents (None)."""
+  pickable = True
+
+  def __init__(self, color='blue'):
+    super().__init__('box', color)
+
+  def toggle(self, env, pos, carrying=None):
+    env.grid.set(pos[0], pos[1], None)
+    return True
+
+
 class Door(Thing):
   """multigrid.py:109-122 on top of minigrid.Door."""
 
@@ -149,6 +161,8 @@ def decode_cell(t, c, s):
     return Key(IDX_COLOR[int(c)])
   if kind == 'ball':
     return Ball(IDX_COLOR[int(c)])
+  if kind == 'box':
+    return Box(IDX_COLOR[int(c)])
   if kind == 'door':
     return Door(IDX_COLOR[int(c)], s == 0, s == 2)
   raise ValueError(kind)
@@ -270,19 +284,26 @@ class PyRefEnv:
     self.agent_pos = [None] * self.n_agents
     self.agent_dir = [None] * self.n_agents
     self.done = [False] * self.n_agents
+    self._gen_grid()
+    self.carrying = [None] * self.n_agents
+    self.step_count = 0
+    return self.gen_obs()
+
+  def _gen_grid(self):
+    """Fixed layout + agents anywhere (cluttered.py:25-40 with fixed_environment)."""
     self.grid = CellGrid(self.width, self.height)
     for y in range(self.height):
       for x in range(self.width):
         self.grid.set(x, y, decode_cell(*self.layout[y, x]))
     for a in range(self.n_agents):
       self.place_one_agent(a)
-    self.carrying = [None] * self.n_agents
-    self.step_count = 0
-    return self.gen_obs()
 
-  def place_obj(self, obj):
+  def place_obj(self, obj, size=None):
+    if size is None:
+      size = (self.grid.width, self.grid.height)
     while True:
-      pos = np.array((self.rand_int(0, self.grid.width), self.rand_int(0, self.grid.height)))
+      pos = np.array((self.rand_int(0, min(size[0], self.grid.width)),
+                      self.rand_int(0, min(size[1], self.grid.height))))
       if self.grid.get(*pos) is not None:
         continue
       if any(np.array_equal(pos, p) for p in self.agent_pos):
@@ -291,9 +312,9 @@ class PyRefEnv:
     self.grid.set(pos[0], pos[1], obj)
     return pos
 
-  def place_one_agent(self, agent_id, agent_obj=None):
+  def place_one_agent(self, agent_id, agent_obj=None, size=None):
     self.agent_pos[agent_id] = None
-    pos = self.place_obj(None)
+    pos = self.place_obj(None, size=size)
     self.agent_pos[agent_id] = pos
     self.agent_dir[agent_id] = self.rand_int(0, 4)
     if not agent_obj:
@@ -432,6 +453,42 @@ class PyRefEnv:
       images.append(grid.encode(mask))
       dirs.append(self.agent_dir[a])
     return {'image': images, 'direction': dirs}
+
+
+class PyDoorKeyEnv(PyRefEnv):
+  """DoorKeyEnv (multigrid_envs/doorkey.py:27-86): random vertical wall with a locked yellow door,
+  yellow key and agents on its left side, goal bottom-right; view 7, max_steps 10*size^2."""
+
+  def __init__(self, size=8, n_agents=3, view_size=7, **kw):
+    self.size = size
+    layout = np.zeros((size, size, 3), np.uint8)
+    super().__init__(layout, n_agents=n_agents, view_size=view_size, max_steps=10 * size * size, **kw)
+
+  def _gen_grid(self):
+    w = h = self.size
+    self.grid = CellGrid(w, h)
+    for i in range(w):                                   # wall_rect (doorkey.py:41)
+      self.grid.set(i, 0, Wall())
+      self.grid.set(i, h - 1, Wall())
+    for j in range(h):
+      self.grid.set(0, j, Wall())
+      self.grid.set(w - 1, j, Wall())
+    self.grid.set(w - 2, h - 2, Goal())                  # :44
+    start_idx = 2 if w <= 5 else 3                       # :47-50
+    self.split_idx = self.rand_int(start_idx, w - 2)     # :51
+    for j in range(h):                                   # vert_wall(split_idx, 0) :52
+      self.grid.set(self.split_idx, j, Wall())
+    for a in range(self.n_agents):                       # place_agent(size=(split_idx, height)) :56
+      self.place_one_agent(a)
+    door_idx = self.rand_int(1, w - 2)                   # :59
+    self.grid.set(self.split_idx, door_idx, Door('yellow', is_locked=True))   # :60-61
+    self.key_pos = self.place_obj(Key('yellow'), size=(self.split_idx, h))    # :64-65
+    self.door_idx = door_idx
+
+  def place_one_agent(self, agent_id, agent_obj=None, size=None):
+    if size is None:                                     # doorkey.py:77-78
+      size = (self.split_idx, self.height)
+    return super().place_one_agent(agent_id, agent_obj=agent_obj, size=size)
 
 
 class V8Shaper:

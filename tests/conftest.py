@@ -24,3 +24,10 @@ def empty_cells():
   """Appendix-B synthetic map: border walls, goal (13,13), no clutter."""
   from multigrid_amd import layouts
   return layouts.empty_bordered(15, 15, goal=(13, 13))
+
+
+@pytest.fixture(scope='session')
+def playground_cells():
+  """Synthetic 9x9 map with keys, balls, boxes, doors, floor, lava and goals (mutable-grid tests)."""
+  from multigrid_amd import layouts
+  return layouts.object_playground()

@@ -19,19 +19,19 @@ class InjectedPyEnv(py_ref_env.PyRefEnv):
     assert lo <= v < hi
     return v
 
-  def place_one_agent(self, agent_id, agent_obj=None):
+  def place_one_agent(self, agent_id, agent_obj=None, size=None):
     src = self._spawn if self._spawn is not None else self._respawn
     self._queue = list(src[agent_id])
-    pos = super().place_one_agent(agent_id, agent_obj=agent_obj)
+    pos = super().place_one_agent(agent_id, agent_obj=agent_obj, size=size)
     # the injected draw must have been accepted at the first try
     if self._queue:
       self.bad_draw = True
     return pos
 
-  def place_obj(self, obj):
+  def place_obj(self, obj, size=None):
     # an injected position that the rejection loop refuses would pop an empty queue
     try:
-      return super().place_obj(obj)
+      return super().place_obj(obj, size=size)
     except IndexError:
       self.bad_draw = True
       raise
