@@ -56,6 +56,24 @@ extern "C" {
 #define MG_PATH_GENERIC 1
 #define MG_PATH_TABLE   2
 
+/* env_kind: what _gen_grid does at every reset.
+ *   STATIC  = one fixed layout shared by all envs (mg_set_static_map), agents spawn anywhere
+ *             (ClutteredMultiGridFixed15x15, cluttered.py:47-63).  A layout of only empty/wall/goal/lava
+ *             cells runs the shared-map kernels; a layout that also holds keys, balls, boxes, doors or
+ *             floor tiles gives every env its own mutable copy (the "mutable-grid" kernel below).
+ *   DOORKEY = DoorKeyEnv._gen_grid (multigrid_envs/doorkey.py:34-86) drawn on device per env and per
+ *             reset: border walls, goal at (W-2,H-2), a wall column at a random split with a locked
+ *             yellow door, agents and a yellow key left of it.  No map upload; W == H >= 5. */
+#define MG_KIND_STATIC  0
+#define MG_KIND_DOORKEY 1
+
+/* One-byte cell kind of the mutable per-env grids (mg_buffers.grid, carried objects):
+ * 0 = nothing, door = 128 + color*4 + state, any other object = type*8 + color.  Agents are not
+ * stored in the grid (their cells read 0): the reference keeps an Agent object in the cell, which
+ * move_agent / agent_is_done always replace by None when the agent leaves (multigrid.py:817-847). */
+#define MG_KIND_ID(type, color, state) ((type) == MG_T_DOOR ? 128 + (color) * 4 + (state) : \
+                                        ((type) <= MG_T_EMPTY || (type) == MG_T_AGENT) ? 0 : (type) * 8 + (color))
+
 /* cell encoding = gym-minigrid OBJECT_TO_IDX / COLOR_TO_IDX / door state */
 #define MG_T_UNSEEN 0
 #define MG_T_EMPTY  1
@@ -71,7 +89,7 @@ extern "C" {
 
 /* bits of the device error word (mg_check_errors) */
 #define MG_ERR_BAD_ACTION   1u  /* action outside [0,6]   (multigrid.py:902 assert) */
-#define MG_ERR_BAD_RESPAWN  2u  /* injected respawn/spawn cell occupied or out of range */
+#define MG_ERR_BAD_RESPAWN  2u  /* injected respawn/spawn/object cell occupied or out of range, or bad injected layout draw */
 #define MG_ERR_BAD_ORDER    4u  /* injected order is not a permutation */
 #define MG_ERR_MISSING_DRAW 8u  /* replay step needed a respawn/spawn that was not injected */
 
@@ -90,7 +108,7 @@ typedef struct mg_config {
                                 kernel and the obs written is the post-reset obs (gym vector
                                 autoreset; v7_stable_goal_focused_ppo.py:334-340 is the only
                                 reference precedent).  0: reference behaviour, caller resets. */
-  int32_t reserved0;
+  int32_t env_kind;          /* MG_KIND_* */
   int32_t emit_env_reward;   /* 1: also write the unshaped env reward (mg_buffers.env_reward) */
   int32_t kernel_path;       /* MG_PATH_AUTO (default), or force MG_PATH_GENERIC / MG_PATH_TABLE */
   int64_t n_envs;            /* envs held by THIS handle (this GPU's shard) */
@@ -116,7 +134,16 @@ typedef struct mg_buffers {
                               x:6 | y:6<<6 | dir:2<<12 | prev_x:6<<14 | prev_y:6<<20 | valid<<26 | stationary:3<<27
                             (post-step, post-respawn position = what v8 reads as env.agent_pos[a], v8:242;
                             prev_x, prev_y, valid, stationary = v8 shaper state, v8:127-129, the count saturating at 7
-                            because only "> 3" is ever tested, v8:202); word A = step_count | agent done bits<<16 */
+                            because only "> 3" is ever tested, v8:202); word A = step_count | agent done bits<<16
+                            | (DOORKEY only) split_idx<<24, the width of the region agents (re)spawn in (doorkey.py:77-78) */
+  /* mutable-grid handles only (mutable_grid != 0), NULL / 0 otherwise: */
+  uint32_t* carry;       /* [env_stride]: byte a = kind id of the object agent a carries, 0 = nothing (multigrid.py:490, 926-951) */
+  uint32_t* grid;        /* [env_stride/64][grid_words][64]: dword j of env n at ((n/64)*grid_words + j)*64 + n%64;
+                            byte b of dword j = kind id of cell index 4j+b = y*W + x.  (One wavefront moves its 64 envs'
+                            grids between HBM and LDS as grid_words fully coalesced 256-byte rows; use mg_export_grid for a
+                            plain [n][H*W] copy.) */
+  int32_t  grid_words;   /* ceil(W*H/4) */
+  int32_t  mutable_grid;
 } mg_buffers;
 
 typedef struct mg_handle mg_handle;
@@ -130,9 +157,11 @@ int mg_destroy(mg_handle* h);
 
 /* Result of _gen_grid's static part (cluttered.py:25-36): one layout shared by every env.
  * cells = host pointer, uint8[W*H*3] indexed [(y*W+x)*3 + c] = (type,color,state).
- * Only empty/wall/goal/lava cells are accepted (MG_EUNSUPPORTED otherwise): the shared map
- * is immutable, which holds for exactly these object kinds (nothing pickable, nothing
- * toggleable, nothing an agent can walk onto and destroy — multigrid.py:842-845,926-961). */
+ * With only empty/wall/goal/lava cells the map stays shared and immutable (nothing pickable, nothing
+ * toggleable, nothing an agent can walk onto and destroy — multigrid.py:842-845,926-961).  Any key,
+ * ball, box (empty), door or floor cell switches the handle to the mutable-grid kernel: every reset
+ * copies the layout into the env's own grid (mg_buffers.grid) and step applies pickup / drop / toggle /
+ * overlap to it (multigrid.py:926-961, 112-122, 834-847).  MG_EINVAL on a DOORKEY handle (no map). */
 int mg_set_static_map(mg_handle* h, const uint8_t* cells);
 
 /* env.reset() (multigrid.py:466-501) for every env whose mask byte is non-zero (mask = device
@@ -159,6 +188,20 @@ int mg_step(mg_handle* h, const void* actions);
  *   reset_spawn = same layout, used when auto_reset fires; may be NULL when auto_reset == 0 */
 int mg_step_replay(mg_handle* h, const void* actions, const uint8_t* order,
                    const int8_t* respawn, const int8_t* reset_spawn);
+
+/* Mutable-grid replay (DoorKey / maps with objects): mg_reset_inject / mg_step_replay plus the two
+ * extra draw streams those envs have.  Any of the extra pointers may be NULL (drawn on device then).
+ *   gen / reset_gen = device int8[env_stride][4] = (split_idx, door_idx, key_x, key_y): the layout draws of
+ *             DoorKeyEnv._gen_grid (doorkey.py:51,59,64-65) for a reset / for the auto-reset of this step
+ *   objdrop = device int8[env_stride][A][4] = (x, y, 0, 0): where place_obj put the object agent a carried
+ *             when it finished this step (multigrid.py:827-829), x = -1 if none recorded */
+int mg_reset_inject_dyn(mg_handle* h, const uint8_t* env_mask, const int8_t* spawn, const int8_t* gen);
+int mg_step_replay_dyn(mg_handle* h, const void* actions, const uint8_t* order, const int8_t* respawn,
+                       const int8_t* objdrop, const int8_t* reset_spawn, const int8_t* reset_gen);
+
+/* env.grid as plain per-env arrays (multigrid.py:281-319 Grid.grid minus the Agent objects):
+ * out = device uint8[n_envs][H*W], out[n][y*W+x] = kind id.  Mutable-grid handles only. */
+int mg_export_grid(mg_handle* h, uint8_t* out);
 
 /* Synthetic-rollout step: like mg_step but the actions are drawn on device too
  * (uniform in [0,6], the "random actions" of BASELINE.json configs) and also stored to

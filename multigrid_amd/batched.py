@@ -32,11 +32,19 @@ def _alias(ptr, shape, typestr, device):
 class BatchedMultiGrid:
   def __init__(self, cells, n_envs, n_agents=3, view_size=5, max_steps=100, see_through_walls=False,
                competitive=False, shaping='v8', auto_reset=True, device=0, seed=0,
-               env_id_base=0, emit_env_reward=False, use_torch_stream=True, kernel_path='auto'):
+               env_id_base=0, emit_env_reward=False, use_torch_stream=True, kernel_path='auto',
+               kind='static', size=None):
+    """kind='static': `cells` uint8[H, W, 3] is the layout every reset starts from (objects allowed).
+    kind='doorkey': `cells` is None and `size` the grid size; layouts are drawn on device."""
     self.L = _lib.load()
-    cells = np.ascontiguousarray(cells, dtype=np.uint8)
-    assert cells.ndim == 3 and cells.shape[2] == 3, 'cells must be uint8[H, W, 3]'
-    self.height, self.width = int(cells.shape[0]), int(cells.shape[1])
+    self.kind = kind
+    if kind == 'static':
+      cells = np.ascontiguousarray(cells, dtype=np.uint8)
+      assert cells.ndim == 3 and cells.shape[2] == 3, 'cells must be uint8[H, W, 3]'
+      self.height, self.width = int(cells.shape[0]), int(cells.shape[1])
+    else:
+      assert cells is None and size is not None, 'generated kinds take size=, not cells'
+      self.height = self.width = int(size)
     self.n_envs, self.n_agents, self.view_size, self.max_steps = int(n_envs), int(n_agents), int(view_size), int(max_steps)
     self.device_index = int(device)
     self.device = torch.device('cuda', self.device_index)
@@ -44,14 +52,16 @@ class BatchedMultiGrid:
         width=self.width, height=self.height, n_agents=n_agents, view_size=view_size, max_steps=max_steps,
         see_through_walls=int(see_through_walls), competitive=int(competitive),
         shaping_kind={None: 0, 'none': 0, 'v8': 1}[shaping], auto_reset=int(auto_reset),
-        reserved0=0, emit_env_reward=int(emit_env_reward),
+        env_kind={'static': _lib.KIND_STATIC, 'doorkey': _lib.KIND_DOORKEY}[kind],
+        emit_env_reward=int(emit_env_reward),
         kernel_path={'auto': 0, 'generic': 1, 'table': 2}[kernel_path],
         n_envs=n_envs, env_id_base=env_id_base, seed=seed)
     self.h = C.c_void_p()
     _lib.check(self.L.mg_create(C.byref(cfg), self.device_index, C.byref(self.h)))
     self.cfg = cfg
     self.cells = cells
-    _lib.check(self.L.mg_set_static_map(self.h, cells.ctypes.data_as(C.c_void_p)))
+    if kind == 'static':
+      _lib.check(self.L.mg_set_static_map(self.h, cells.ctypes.data_as(C.c_void_p)))
     if use_torch_stream:
       s = torch.cuda.current_stream(self.device)
       _lib.check(self.L.mg_set_stream(self.h, C.c_void_p(s.cuda_stream)))
@@ -72,6 +82,13 @@ class BatchedMultiGrid:
     self.env_reward = None if self._env_reward is None else self._env_reward[:, :n]
     self.done = self._dir_done[:n, A]            # collective done     uint8[N]    (strided view)
     self.env_state = self._env_state[:n]         # int32[N, A+1], packing in include/mgrid.h
+    # mutable-grid handles (DoorKey, layouts with objects): carried objects and the per-env grids
+    self.mutable_grid = bool(b.mutable_grid)
+    self.carry = self.grid_blocked = None
+    if self.mutable_grid:
+      self.grid_words = int(b.grid_words)
+      self.carry = _alias(b.carry, (S,), '<i4', dev)[:n]                        # byte a = kind agent a carries
+      self.grid_blocked = _alias(b.grid, (S // 64, self.grid_words, 64, 4), '|u1', dev)   # layout in include/mgrid.h
     # action buffer in the layout the kernel reads: one dword per env, byte a = agent a's action.
     # Policies write `env.actions[:N, a]`; `step()` with no argument consumes it.
     self.actions = torch.full((S, 4), 6, dtype=torch.uint8, device=dev)
@@ -157,10 +174,32 @@ class BatchedMultiGrid:
             'grid_blocks': v[2].value, 'lds_bytes': v[3].value}
 
   # ---- reference contract -------------------------------------------------------------------
-  def reset(self, mask=None, spawn=None):
-    """env.reset() for all envs (or those in `mask`).  spawn: int8[A, N, 4] (x,y,dir,0) to inject."""
+  def grid_kinds(self):
+    """uint8[N, H, W] kind ids of every env's grid (mg_export_grid): env.grid minus the agents."""
+    out = torch.empty((self.n_envs, self.height, self.width), dtype=torch.uint8, device=self.device)
+    _lib.check(self.L.mg_export_grid(self.h, C.c_void_p(out.data_ptr())))
+    return out
+
+  def _gen_ptr(self, gen):
+    if gen is None:
+      return None, None
+    g = torch.as_tensor(gen, device=self.device).to(torch.int8)
+    if g.shape[0] != self.stride:
+      buf = torch.zeros((self.stride, 4), dtype=torch.int8, device=self.device)
+      buf[:g.shape[0]] = g
+      g = buf
+    g = g.contiguous()
+    return C.c_void_p(g.data_ptr()), g
+
+  def reset(self, mask=None, spawn=None, gen=None):
+    """env.reset() for all envs (or those in `mask`).  spawn: int8[A, N, 4] (x,y,dir,0) to inject;
+    gen: int8[N, 4] (split, door, key_x, key_y) DoorKey layout draws to inject."""
     mp, _m = self._mask_ptr(mask)
-    if spawn is None:
+    if gen is not None or (spawn is not None and self.mutable_grid):
+      sp, _s = self._env_major(spawn, torch.int8, self.n_agents, (4,))
+      gp, _g = self._gen_ptr(gen)
+      _lib.check(self.L.mg_reset_inject_dyn(self.h, mp, sp, gp))
+    elif spawn is None:
       _lib.check(self.L.mg_reset(self.h, mp))
     else:
       sp, _s = self._env_major(spawn, torch.int8, self.n_agents, (4,))
@@ -177,12 +216,17 @@ class BatchedMultiGrid:
     _lib.check(self.L.mg_step(self.h, ap))
     return self.obs(), self.reward, self.done, {}
 
-  def step_replay(self, actions, order, respawn, reset_spawn=None):
+  def step_replay(self, actions, order, respawn, reset_spawn=None, objdrop=None, reset_gen=None):
     ap, _a = self._actions_ptr(actions)
     op, _o = self._env_major(order, torch.uint8, 4)
     rp, _r = self._env_major(respawn, torch.int8, self.n_agents, (4,))
     sp, _s = self._env_major(reset_spawn, torch.int8, self.n_agents, (4,))
-    _lib.check(self.L.mg_step_replay(self.h, ap, op, rp, sp))
+    if self.mutable_grid:
+      dp, _d = self._env_major(objdrop, torch.int8, self.n_agents, (4,))
+      gp, _g = self._gen_ptr(reset_gen)
+      _lib.check(self.L.mg_step_replay_dyn(self.h, ap, op, rp, dp, sp, gp))
+    else:
+      _lib.check(self.L.mg_step_replay(self.h, ap, op, rp, sp))
     return self.obs(), self.reward, self.done, {}
 
   def step_random(self, actions_out=None):

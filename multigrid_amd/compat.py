@@ -24,6 +24,34 @@ class _GridView:
     return _GoalCell() if self._cells[j, i, 0] == 8 else None
 
 
+_TYPE_NAMES = {2: 'wall', 3: 'floor', 4: 'door', 5: 'key', 6: 'ball', 7: 'box', 8: 'goal', 9: 'lava'}
+_COLOR_NAMES = ('red', 'green', 'blue', 'purple', 'yellow', 'grey')
+
+
+class _Cell:
+  """What env.grid.get(i, j) returns on a mutable grid: type / color / door state of a kind id."""
+
+  def __init__(self, kind):
+    if kind >= 128:
+      t, c, st = 4, ((kind - 128) >> 2) & 7, kind & 3
+    else:
+      t, c, st = kind >> 3, kind & 7, 0
+    self.type = _TYPE_NAMES.get(t, 'unknown')
+    self.color = _COLOR_NAMES[c] if c < len(_COLOR_NAMES) else 'unknown'
+    self.is_open, self.is_locked = (st == 0, st == 2) if t == 4 else (False, False)
+
+
+class _LiveGridView:
+  """env.grid.get(i, j) on a mutable-grid env: read from the device grid (agents' cells give None)."""
+
+  def __init__(self, batched):
+    self._b = batched
+
+  def get(self, i, j):
+    k = int(self._b.grid_kinds()[0, j, i].item())
+    return None if k == 0 else _Cell(k)
+
+
 class RefCompatEnv:
   """One env (N = 1) with the reference's list-of-arrays contract; rewards are the unshaped env
   rewards unless the batched env was built with shaping='v8'."""
@@ -35,7 +63,7 @@ class RefCompatEnv:
     self.width, self.height = batched.width, batched.height
     self.max_steps = batched.max_steps
     self.agent_view_size = batched.view_size
-    self.grid = _GridView(batched.cells)
+    self.grid = _LiveGridView(batched) if batched.mutable_grid else _GridView(batched.cells)
 
   def _obs(self):
     img = self.b.obs_image[:, 0].cpu().numpy()

@@ -1,0 +1,363 @@
+// mg_dyn.h — the mutable-grid kernel: DoorKey and fixed layouts that hold keys,
+// balls, boxes, doors or floor tiles.  Included by mgrid.hip inside its anonymous namespace; shares
+// Params, Philox, the agent-order / action draws, the v8 shaper and the obs staging with the
+// shared-map kernel.
+//
+// Every env owns a W*H grid of one-byte kind ids (include/mgrid.h MG_KIND_ID) plus one "carry" word
+// (byte a = what agent a carries).  HBM keeps the grids chunk-blocked, [chunk][dword j][64 lanes],
+// so a wavefront moves its 64 envs' grids to and from LDS as GW fully coalesced 256-byte rows, and
+// in LDS lane l's dword j sits at bank (j*64 + l) % 64 = l: every per-lane byte access of the step
+// is conflict free whatever cell each env touches.  Agents are not stored in the grid; their cells
+// read 0 and they are overlaid from the packed position word, as on the shared-map path.
+//
+// Reference: envs/gym_multigrid/multigrid.py:815-961 (agent_is_done, move_agent, _forward, _pickup,
+// _drop, _toggle), :112-122 (Door.toggle), :997-1035 (gen_obs_grid with the carried object on the
+// agent's own cell), multigrid_envs/doorkey.py:34-86 (generator, spawn region).
+
+constexpr uint32_t F_OVERLAP = 1u << 28;   // can_overlap(): floor, open door (goal/lava are F_KILL)
+constexpr uint32_t F_PICKUP = 1u << 29;    // can_pickup(): key, ball, box
+constexpr uint32_t F_DOOR = 1u << 30;
+constexpr uint32_t F_BOX = 1u << 31;
+constexpr uint32_t K_WALL = MG_T_WALL * 8 + 5;                 // grey wall: wall_rect and Grid.slice's padding
+constexpr uint32_t K_GOAL = MG_T_GOAL * 8 + 1;                 // green goal
+constexpr uint32_t K_DOOR_YELLOW_LOCKED = 128 + 4 * 4 + 2;     // Door('yellow', is_locked=True), doorkey.py:60
+constexpr uint32_t K_KEY_YELLOW = MG_T_KEY * 8 + 4;            // Key('yellow'), doorkey.py:65
+enum { P_GEN = 4, P_KEY = 5, P_OBJDROP = 6 };
+
+// kind id -> encode() triple (type | color<<8 | state<<16) + behaviour flags.  256 entries, built
+// once per workgroup into LDS.
+__host__ __device__ inline uint32_t kind_word(uint32_t k) {
+  if (k == 0u) return (uint32_t)MG_T_EMPTY | F_FREE;
+  if (k >= 128u) {
+    const uint32_t color = ((k - 128u) >> 2) & 7u, state = k & 3u;
+    uint32_t w = (uint32_t)MG_T_DOOR | (color << 8) | (state << 16) | F_DOOR;
+    w |= (state == 0u) ? F_OVERLAP : F_OPAQUE;                 // Door.can_overlap / see_behind = is_open
+    return w;
+  }
+  const uint32_t type = k >> 3, color = k & 7u;
+  uint32_t w = type | (color << 8);
+  switch (type) {
+    case MG_T_WALL: w |= F_OPAQUE; break;
+    case MG_T_FLOOR: w |= F_OVERLAP; break;
+    case MG_T_KEY: case MG_T_BALL: w |= F_PICKUP; break;
+    case MG_T_BOX: w |= F_PICKUP | F_BOX; break;
+    case MG_T_GOAL: w |= F_KILL | F_GOAL; break;
+    case MG_T_LAVA: w |= F_KILL; break;
+    default: break;                                            // a solid, inert object
+  }
+  return w;
+}
+
+// g = LDS byte address of this lane's dword 0; cell index ci = y*W + x
+__device__ __forceinline__ uint32_t g_get(const uint8_t* g, int ci) { return g[((ci >> 2) << 8) | (ci & 3)]; }
+__device__ __forceinline__ void g_set(uint8_t* g, int ci, uint32_t k) { g[((ci >> 2) << 8) | (ci & 3)] = (uint8_t)k; }
+
+// place_obj's acceptance test (multigrid.py:603-613) inside x < xmax on this env's own grid
+template <int A>
+__device__ __forceinline__ bool dyn_free(const Params& p, const uint8_t* g, uint64_t pd, uint32_t occ, int x, int y, int xmax) {
+  if ((unsigned)x >= (unsigned)min(xmax, p.W) || (unsigned)y >= (unsigned)p.H) return false;
+  if (g_get(g, y * p.W + x) != 0u) return false;
+  const uint32_t pos = (uint32_t)x | ((uint32_t)y << 6);
+  bool ok = true;
+#pragma unroll
+  for (int b = 0; b < A; ++b) ok = ok && !(((occ >> b) & 1u) && (pd_get(pd, b) & AW_POS) == pos);
+  return ok;
+}
+
+// place_obj (multigrid.py:560-627) for an agent (is_agent: a direction is drawn too, :665-666) or an
+// object, in the rectangle x < xmax.  Injected draw (have_inj, injw = int8x4 x,y,dir,0) or Philox
+// rejection sampling keyed (purpose, a, attempt).  Returns x | y<<6 | dir<<12 | MG_ERR_*<<16.
+template <int A>
+__device__ __forceinline__ uint32_t place_dyn(const Params& p, const uint8_t* g, uint64_t pd, uint32_t occ, int a,
+                                              int purpose, int xmax, bool have_inj, uint32_t injw, bool is_agent,
+                                              uint32_t gid) {
+  int x = -1, y = -1, dir = 0;
+  uint32_t err = 0;
+  if (have_inj) {
+    x = (int8_t)(injw & 255u); y = (int8_t)((injw >> 8) & 255u); dir = is_agent ? (int8_t)((injw >> 16) & 255u) : 0;
+    if (x < 0) { err = MG_ERR_MISSING_DRAW; x = -1; }
+    else if (!dyn_free<A>(p, g, pd, occ, x, y, xmax) || (unsigned)dir > 3u) { err = MG_ERR_BAD_RESPAWN; x = -1; }
+  } else {
+    const uint32_t nx = (uint32_t)min(xmax, p.W);
+    for (int k = 0; k < kMaxAttempts; ++k) {
+      const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32),
+                          ((uint32_t)purpose << 28) | ((uint32_t)a << 20) | (uint32_t)k, p.seed_lo, p.seed_hi);
+      const int cx = (int)__umulhi(r.x, nx), cy = (int)__umulhi(r.y, (uint32_t)p.H);
+      if (dyn_free<A>(p, g, pd, occ, cx, cy, xmax)) { x = cx; y = cy; dir = is_agent ? (int)(r.z >> 30) : 0; break; }
+    }
+  }
+  if (x < 0) {   // exit condition of the sampling loop: first free cell in storage order, dir 0
+    dir = 0;
+    for (int j = 0; j < p.H && x < 0; ++j)
+      for (int i = 0; i < p.W && i < xmax; ++i)
+        if (dyn_free<A>(p, g, pd, occ, i, j, xmax)) { x = i; y = j; break; }
+    if (x < 0) { x = 0; y = 0; }
+  }
+  return (uint32_t)x | ((uint32_t)y << 6) | ((uint32_t)dir << 12) | (err << 16);
+}
+
+// gen_obs_grid (multigrid.py:997-1035) from this env's own grid: view cell (vx,vy) = world cell
+// pos + f*(V-1-vy) + r*(vx-V/2); cells outside the grid are Grid.slice's grey walls (:315); the own
+// cell shows the carried object (:1029-1033).
+template <int V>
+__device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, const uint32_t* lut, uint32_t me, uint32_t ck,
+                                         uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t& vm) {
+  const int x = aw_x(me), y = aw_y(me), d = aw_d(me);
+  const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
+  const int rx = -fy, ry = fx;
+  const int x0 = x + fx * (V - 1) - rx * (V / 2), y0 = y + fy * (V - 1) - ry * (V / 2);   // view cell (0,0)
+  uint32_t code[V * V];
+  uint32_t opq[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) opq[j] = 0;
+#pragma unroll
+  for (int vx = 0; vx < V; ++vx)
+#pragma unroll
+    for (int vy = 0; vy < V; ++vy) {
+      const int wx = x0 + vx * rx - vy * fx, wy = y0 + vx * ry - vy * fy;
+      const bool inb = (unsigned)wx < (unsigned)p.W && (unsigned)wy < (unsigned)p.H;
+      const uint32_t k = g_get(g, inb ? wy * p.W + wx : 0);
+      const uint32_t w = lut[inb ? k : K_WALL];
+      code[vx * V + vy] = w & 0xFFFFFFu;
+      opq[vy] |= ((w >> 24) & 1u) << vx;
+    }
+  pack_view<V>(code, opq, p.see_through != 0, lut[ck] & 0xFFFFFFu, s, vm);
+}
+
+// One chunk (64 envs) of one step()/reset() on mutable grids.
+template <int A, int V>
+__device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, const uint32_t* lut, const uint32_t* base,
+                                          uint32_t* stage, uint32_t* gw, int lane, int64_t env0, uint32_t& err_acc) {
+  constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
+  const int64_t n = env0 + lane;
+  const bool active = n < p.n_envs;
+  const uint32_t gid = (uint32_t)(p.gid_base + (uint64_t)n);
+  const uint32_t all = (1u << A) - 1u;
+
+  // ---- this wave's 64 grids: HBM -> LDS (lane l moves dword (j, l): its own env's) ------------
+  uint32_t* const ghbm = p.grid + (env0 >> 6) * (int64_t)p.GW * kWave;
+  for (int j = 0; j < p.GW; ++j) gw[j * kWave + lane] = ghbm[j * kWave + lane];
+  uint8_t* const g = reinterpret_cast<uint8_t*>(gw + lane);
+
+  uint64_t pd = 0;
+  uint32_t shw[A];
+  uint32_t actw = 0, err = 0;
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    const uint32_t w = p.env_state[n * (A + 1) + a];
+    const uint32_t cx = min(w & 63u, (uint32_t)(p.W - 1)), cy = min((w >> 6) & 63u, (uint32_t)(p.H - 1));
+    pd |= (uint64_t)(cx | (cy << 6) | (w & 0x3000u)) << (14 * a);
+    shw[a] = w & ~AW_POSDIR;
+  }
+  uint32_t st = p.env_state[n * (A + 1) + A];
+  uint32_t carry = p.carry[n];
+  // agents (re)spawn at x < spawn_w: the DoorKey split (doorkey.py:77-78), the whole grid otherwise
+  int spawn_w = p.kind == MG_KIND_STATIC ? p.W : (int)min((st >> 24) & 63u, (uint32_t)p.W);
+  uint32_t done_flag = 0;
+
+  const bool is_step = p.op == OP_STEP;
+  if (is_step) {
+    if (p.random_actions) actw = draw_actions<A>(p, n, gid, active);
+    else {
+      const uint32_t aw = p.actions[n];
+#pragma unroll
+      for (int a = 0; a < A; ++a) actw |= min((aw >> (8 * a)) & 255u, 7u) << (3 * a);
+    }
+    uint32_t step = (st & 0xFFFFu) + 1u;                                        // multigrid.py:968
+    uint32_t dbits = (st >> 16) & all;
+    if (step > 0xFFFFu) step = 0xFFFFu;
+    const uint32_t ordw = agent_order<A, false>(p, n, gid, active, err);
+
+    uint32_t gbits = 0;
+#pragma unroll 1
+    for (int k = 0; k < A; ++k) {                                               // step_one_agent, multigrid.py:860-904
+      const int a = (int)((ordw >> (2 * k)) & 3u);
+      const uint32_t s = pd_get(pd, a);
+      const uint32_t act = (actw >> (3 * a)) & 7u;
+      const int x = aw_x(s), y = aw_y(s), d = aw_d(s);
+      const int fx = x + (d == 0) - (d == 2), fy = y + (d == 1) - (d == 3);     // front_pos, pre-action
+      const uint32_t fpos = (uint32_t)fx | ((uint32_t)fy << 6);
+      bool blocked = false;                                                     // another agent in front
+#pragma unroll
+      for (int b = 0; b < A; ++b) blocked = blocked || (b != a && (pd_get(pd, b) & AW_POS) == fpos);
+      // agents live inside the border wall, so the front cell is on the grid; a map without a
+      // border makes the reference fault (Grid.get asserts) — here the outside reads as wall
+      const bool inb = (unsigned)fx < (unsigned)p.W && (unsigned)fy < (unsigned)p.H;
+      const int ci = inb ? fy * p.W + fx : 0;
+      const uint32_t kf = inb ? g_get(g, ci) : K_WALL;
+      const uint32_t fl = lut[kf];
+      const uint32_t ck = (carry >> (8 * a)) & 255u;
+      const int nd = (act == 0u) ? ((d + 3) & 3) : (act == 1u) ? ((d + 1) & 3) : d;   // :867-876
+      uint32_t npd = (s & AW_POS) | ((uint32_t)nd << 12);
+      if (act == 2u) {                                                          // _forward :906-924
+        if (!blocked) {
+          if (fl & F_KILL) {                                                    // agent_is_done :815-832
+            dbits |= 1u << a;
+            if (fl & F_GOAL) gbits |= 1u << a;
+            if (ck) {
+              // the carried object is placed anywhere on the grid first (:827-829); the finishing
+              // agent's old cell still counts as occupied (agent_pos is cleared only afterwards, :655)
+              const bool inj = p.objdrop != nullptr;
+              const uint32_t w = place_dyn<A>(p, g, pd, all, a, P_OBJDROP, p.W, inj, inj ? p.objdrop[n * A + a] : 0u, false, gid);
+              g_set(g, aw_y(w) * p.W + aw_x(w), ck);
+              carry &= ~(255u << (8 * a));
+              err |= w >> 16;
+            }
+            const bool inj = p.respawn != nullptr;
+            const uint32_t w = place_dyn<A>(p, g, pd, all & ~(1u << a), a, P_RESPAWN, spawn_w, inj,
+                                            inj ? p.respawn[n * A + a] : 0u, true, gid);
+            npd = w & AW_POSDIR;
+            err |= w >> 16;
+          } else if (fl & (F_FREE | F_OVERLAP)) {                               // move_agent :834-847
+            npd = fpos | ((uint32_t)d << 12);
+            if (fl & F_OVERLAP) g_set(g, ci, 0u);      // the Agent object replaces what was there, for good
+          }
+        }
+      } else if (act == 3u) {                                                   // _pickup :926-938
+        if ((fl & F_PICKUP) && ck == 0u) {
+          carry |= kf << (8 * a);
+          g_set(g, ci, 0u);
+        }
+      } else if (act == 4u) {                                                   // _drop :940-951
+        if ((fl & F_FREE) && !blocked && ck != 0u) {
+          g_set(g, ci, ck);
+          carry &= ~(255u << (8 * a));
+        }
+      } else if (act == 5u) {                                                   // _toggle :953-961
+        if (fl & F_DOOR) {                                                      // Door.toggle :112-122
+          const uint32_t state = kf & 3u, color = ((kf - 128u) >> 2) & 7u;
+          if (state == 2u) {
+            if (ck < 128u && (ck >> 3) == (uint32_t)MG_T_KEY && (ck & 7u) == color) g_set(g, ci, kf & ~3u);
+          } else {
+            g_set(g, ci, kf ^ 1u);
+          }
+        } else if (fl & F_BOX) {
+          g_set(g, ci, 0u);                                                     // Box.toggle: replaced by its (empty) contents
+        }
+      }
+      if (act > 6u) err |= MG_ERR_BAD_ACTION;                                   // assert False :902
+      pd = pd_set(pd, a, npd);
+    }
+    double rgoal = 0.0;
+    if (gbits) rgoal = device_reward(step, p.max_steps);                        // _reward() :883
+    done_flag = (p.competitive && dbits != 0u) || (step >= (uint32_t)p.max_steps);   // :986-993
+
+    double rew[A], out_rew[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      rew[a] = ((gbits >> a) & 1u) ? rgoal : 0.0;
+      out_rew[a] = rew[a];
+      if (p.shaping == MG_SHAPING_V8)
+        shw[a] = v8_shape(p, dist, shw[a], pd_get(pd, a), (actw >> (3 * a)) & 7u, rew[a], out_rew[a]);
+    }
+    st = step | (dbits << 16) | (p.kind == MG_KIND_STATIC ? 0u : (uint32_t)spawn_w << 24);
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        const int64_t i = (int64_t)a * p.stride + n;
+        p.reward[i] = out_rew[a];
+        if (p.env_reward) p.env_reward[i] = rew[a];
+      }
+    }
+  }
+
+  // ---- reset() (multigrid.py:466-501) / auto-reset: _gen_grid on this env's own grid ------------
+  const bool do_reset = (!is_step) ? (p.mask ? (p.mask[active ? n : 0] != 0) : true) : (done_flag && p.auto_reset);
+  if (do_reset) {
+    for (int j = 0; j < p.GW; ++j) gw[j * kWave + lane] = base[j];
+    carry = 0u;                                                                 // multigrid.py:490
+    int door = 1;
+    const bool inj_gen = p.reset_gen != nullptr;
+    const uint32_t genw = inj_gen ? p.reset_gen[n] : 0u;
+    if (p.kind == MG_KIND_DOORKEY) {                                            // doorkey.py:46-52
+      const int start = p.W <= 5 ? 2 : 3;
+      int split;
+      if (inj_gen) { split = (int8_t)(genw & 255u); door = (int8_t)((genw >> 8) & 255u); }
+      else {
+        const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), (uint32_t)P_GEN << 28, p.seed_lo, p.seed_hi);
+        split = start + (int)__umulhi(r.x, (uint32_t)(p.W - 2 - start));        // _rand_int(start_idx, width-2)
+        door = 1 + (int)__umulhi(r.y, (uint32_t)(p.W - 3));                     // _rand_int(1, width-2)
+      }
+      if (split < 1 || split > p.W - 2 || door < 1 || door > p.H - 2) { err |= MG_ERR_BAD_RESPAWN; split = start; door = 1; }
+      for (int j = 0; j < p.H; ++j) g_set(g, j * p.W + split, K_WALL);          // vert_wall(split_idx, 0)
+      spawn_w = split;
+    }
+#pragma unroll 1
+    for (int a = 0; a < A; ++a) {                                               // place_agent, in agent order
+      const bool inj = p.reset_spawn != nullptr;
+      const uint32_t w = place_dyn<A>(p, g, pd, (1u << a) - 1u, a, P_SPAWN, spawn_w, inj,
+                                      inj ? p.reset_spawn[n * A + a] : 0u, true, gid);
+      pd = pd_set(pd, a, w & AW_POSDIR);
+      err |= w >> 16;
+    }
+    if (p.kind == MG_KIND_DOORKEY) {                                            // doorkey.py:58-65
+      g_set(g, door * p.W + spawn_w, K_DOOR_YELLOW_LOCKED);
+      const uint32_t w = place_dyn<A>(p, g, pd, all, 0, P_KEY, spawn_w, inj_gen, genw >> 16, false, gid);
+      g_set(g, aw_y(w) * p.W + aw_x(w), K_KEY_YELLOW);
+      err |= w >> 16;
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) shw[a] = 0u;
+    st = p.kind == MG_KIND_STATIC ? 0u : (uint32_t)spawn_w << 24;
+  }
+
+  if (active) {
+#pragma unroll
+    for (int a = 0; a < A; ++a) p.env_state[n * (A + 1) + a] = shw[a] | pd_get(pd, a);
+    p.env_state[n * (A + 1) + A] = st;
+    p.carry[n] = carry;
+    uint64_t dd = (uint64_t)done_flag << (8 * A);
+#pragma unroll
+    for (int a = 0; a < A; ++a) dd |= (uint64_t)aw_d(pd_get(pd, a)) << (8 * a);
+    if (A + 1 <= 4) reinterpret_cast<uint32_t*>(p.dir_done)[n] = (uint32_t)dd;
+    else reinterpret_cast<uint64_t*>(p.dir_done)[n] = dd;
+    err_acc |= err;
+  }
+  // ---- grids: LDS -> HBM (padding lanes write their own, unused, slots) ------------------------
+  for (int j = 0; j < p.GW; ++j) ghbm[j * kWave + lane] = gw[j * kWave + lane];
+
+  // ---- gen_obs (multigrid.py:1037-1067) --------------------------------------------------------
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    uint32_t s[NW + 1];
+    uint64_t vm;
+    dyn_view<V>(p, g, lut, pd_get(pd, a), (carry >> (8 * a)) & 255u, s, vm);
+    emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB);
+  }
+}
+
+template <int A, int V>
+__global__ __launch_bounds__(256) void mg_dyn_kernel(const Params p) {
+  constexpr int ROWB = ViewGeom<V>::ROWB;
+  extern __shared__ __align__(16) uint8_t smem[];
+  // LDS carve: [stage: nw x 64*ROWB B][grids: nw x GW*256 B][dist LUT: W*H f64][kind LUT: 256 u32][base: GW u32]
+  const int nw = blockDim.x >> 6;
+  uint32_t* stage_all = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* grids = reinterpret_cast<uint32_t*>(smem + (size_t)nw * kWave * ROWB);
+  double* dist = reinterpret_cast<double*>(grids + (size_t)nw * p.GW * kWave);
+  uint32_t* lut = reinterpret_cast<uint32_t*>(dist + p.W * p.H);
+  uint32_t* base = lut + 256;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
+  for (int i = tid; i < 256; i += blockDim.x) lut[i] = kind_word((uint32_t)i);
+  for (int i = tid; i < p.GW; i += blockDim.x) base[i] = p.base_grid[i];
+  for (int i = tid; i < p.W * p.H; i += blockDim.x) dist[i] = p.dist_lut[i];
+  __syncthreads();
+  uint32_t* stage = stage_all + wv * (kWave * ROWB / 4);
+  uint32_t* gw = grids + (size_t)wv * p.GW * kWave;
+  uint32_t err = 0;
+  const int64_t cstride = (int64_t)gridDim.x * nw;
+  for (int64_t c = (int64_t)blockIdx.x * nw + wv; c < p.n_chunks; c += cstride)
+    dyn_chunk<A, V>(p, dist, lut, base, stage, gw, lane, c * kWave, err);
+  if (err) atomicOr(p.err, err);
+}
+
+// mg_export_grid: de-block the per-env grids into plain [n][W*H] byte arrays
+__global__ void export_grid_kernel(const uint32_t* grid, int GW, int cells, int64_t n_envs, uint8_t* out) {
+  const int64_t total = n_envs * cells;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / cells;
+    const int ci = (int)(i - n * cells);
+    const uint32_t w = grid[((n >> 6) * GW + (ci >> 2)) * kWave + (n & 63)];
+    out[i] = (uint8_t)(w >> (8 * (ci & 3)));
+  }
+}

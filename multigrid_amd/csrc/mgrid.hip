@@ -86,6 +86,13 @@ struct Params {
   uint8_t* dir_done;           // [stride][dd_bytes]: dir of agent a at byte a, done at byte A
   uint32_t* env_state;         // [stride][A+1]
   uint32_t* err;
+  // mutable-grid kernel only (mg_dyn.h)
+  int32_t kind, GW;            // MG_KIND_*, grid dwords per env
+  const uint32_t* base_grid;   // [GW] kind ids of the layout every reset starts from
+  const uint32_t* objdrop;     // int8x4 per (env, agent)
+  const uint32_t* reset_gen;   // int8x4 per env
+  uint32_t* carry;             // [stride]
+  uint32_t* grid;              // [n_chunks][GW][64]
 };
 
 struct U4 { uint32_t x, y, z, w; };
@@ -181,37 +188,20 @@ __device__ __forceinline__ uint32_t place_agent(const Params& p, const uint32_t*
 // the host for every (free cell, dir) and is simply fetched from LDS.
 // Output: s[0..NW-1] = the V*V 3-byte codes as a dword stream, vm = visibility bits (vx*V+vy).
 // ---------------------------------------------------------------------------------------------
+// process_vis + own cell + encode: from the V*V cell codes (code[vx*V+vy] = type | color<<8 |
+// state<<16) and the per-row opacity bits (opq[vy] bit vx) to the dword stream and visibility mask.
 template <int V>
-__device__ __forceinline__ void static_view(const Params& p, const uint32_t* map, uint32_t me,
-                                            uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t& vm) {
+__device__ __forceinline__ void pack_view(uint32_t (&code)[V * V], const uint32_t (&opq)[V], bool see_through,
+                                          uint32_t own_code, uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t& vm) {
   constexpr int NW = ViewGeom<V>::NW;
-  const int pad = (p.PW - p.W) >> 1;
-  const int x = aw_x(me), y = aw_y(me), d = aw_d(me);
-  const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
-  const int rx = -fy, ry = fx;
-  const int dr = rx + p.PW * ry, df = fx + p.PW * fy;
-  const int i0 = (y + pad + fy * (V - 1) - ry * (V / 2)) * p.PW + (x + pad + fx * (V - 1) - rx * (V / 2));
-  uint32_t code[V * V];
-  uint32_t opq[V], vis[V];
-#pragma unroll
-  for (int j = 0; j < V; ++j) opq[j] = 0;
-#pragma unroll
-  for (int vx = 0; vx < V; ++vx)
-#pragma unroll
-    for (int vy = 0; vy < V; ++vy) {
-      const uint32_t w = map[i0 + vx * dr - vy * df];
-      code[vx * V + vy] = w & 0xFFFFFFu;
-      opq[vy] |= ((w >> 24) & 1u) << vx;
-    }
-  if (p.see_through) {
+  uint32_t vis[V];
+  if (see_through) {
 #pragma unroll
     for (int j = 0; j < V; ++j) vis[j] = (1u << V) - 1u;
   } else {
     mg_vis_rows<V>(opq, vis);
   }
-  // own cell <- carried object or None, after process_vis (multigrid.py:1029-1033); nothing can
-  // be carried on a static map
-  code[(V / 2) * V + (V - 1)] = (uint32_t)MG_T_EMPTY;
+  code[(V / 2) * V + (V - 1)] = own_code;
 #pragma unroll
   for (int i = 0; i <= NW; ++i) s[i] = 0;
   vm = 0;
@@ -227,6 +217,33 @@ __device__ __forceinline__ void static_view(const Params& p, const uint32_t* map
       s[wi] |= v << sh;
       if (sh > 8) s[wi + 1] |= v >> (32 - sh);
     }
+}
+
+template <int V>
+__device__ __forceinline__ void static_view(const Params& p, const uint32_t* map, uint32_t me,
+                                            uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t& vm) {
+  constexpr int NW = ViewGeom<V>::NW;
+  const int pad = (p.PW - p.W) >> 1;
+  const int x = aw_x(me), y = aw_y(me), d = aw_d(me);
+  const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
+  const int rx = -fy, ry = fx;
+  const int dr = rx + p.PW * ry, df = fx + p.PW * fy;
+  const int i0 = (y + pad + fy * (V - 1) - ry * (V / 2)) * p.PW + (x + pad + fx * (V - 1) - rx * (V / 2));
+  uint32_t code[V * V];
+  uint32_t opq[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) opq[j] = 0;
+#pragma unroll
+  for (int vx = 0; vx < V; ++vx)
+#pragma unroll
+    for (int vy = 0; vy < V; ++vy) {
+      const uint32_t w = map[i0 + vx * dr - vy * df];
+      code[vx * V + vy] = w & 0xFFFFFFu;
+      opq[vy] |= ((w >> 24) & 1u) << vx;
+    }
+  // own cell <- carried object or None, after process_vis (multigrid.py:1029-1033); nothing can
+  // be carried on a static map
+  pack_view<V>(code, opq, p.see_through != 0, (uint32_t)MG_T_EMPTY, s, vm);
 }
 
 template <int V>
@@ -364,6 +381,90 @@ __device__ __forceinline__ void wait_chunk(ChunkIn& in) {
                : "memory");
 }
 
+// "random actions" of the synthetic rollouts: uniform in [0,6] per agent, 3 bits each; also
+// stored to actions_out in the layout mg_step reads.
+template <int A>
+__device__ __forceinline__ uint32_t draw_actions(const Params& p, int64_t n, uint32_t gid, bool active) {
+  const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), (uint32_t)P_ACTION << 28, p.seed_lo, p.seed_hi);
+  const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+  uint32_t actw = 0;
+#pragma unroll
+  for (int a = 0; a < A; ++a) actw |= __umulhi(rr[a & 3], 7u) << (3 * a);
+  if (p.actions_out && active) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int a = 0; a < A; ++a) w |= ((actw >> (3 * a)) & 7u) << (8 * a);
+    p.actions_out[n] = w;
+  }
+  return actw;
+}
+
+// Agent order of this step (multigrid.py:973-974), packed 2 bits per slot: injected, or a
+// Philox Fisher-Yates.
+template <int A, bool FAST>
+__device__ __forceinline__ uint32_t agent_order(const Params& p, int64_t n, uint32_t gid, bool active, uint32_t& err) {
+  uint32_t ordw = 0;
+#pragma unroll
+  for (int k = 0; k < A; ++k) ordw |= (uint32_t)k << (2 * k);
+  if (!FAST && p.order) {
+    uint32_t seen = 0, w = 0;
+    const uint32_t ow = p.order[n];
+#pragma unroll
+    for (int k = 0; k < A; ++k) {
+      const uint32_t o = (ow >> (8 * k)) & 255u;
+      if (o < (uint32_t)A) seen |= 1u << o;
+      w |= (o & 3u) << (2 * k);
+    }
+    if (seen != (1u << A) - 1u) { if (active) err |= MG_ERR_BAD_ORDER; }
+    else ordw = w;
+  } else if (A > 1 && MG_ABL != 3) {
+    const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), (uint32_t)P_ORDER << 28, p.seed_lo, p.seed_hi);
+    const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+    // Fisher-Yates from the top, as np.random.shuffle does: swap slots i and j = rand(i+1)
+#pragma unroll
+    for (int i = A - 1, w = 0; i >= 1; --i, ++w) {
+      const uint32_t j = __umulhi(rr[w & 3], (uint32_t)(i + 1));
+      const uint32_t oi = (ordw >> (2 * i)) & 3u, oj = (ordw >> (2 * j)) & 3u;
+      ordw = (ordw & ~(3u << (2 * i)) & ~(3u << (2 * j))) | (oi << (2 * j));
+      ordw = (ordw & ~(3u << (2 * i))) | (oj << (2 * i));
+    }
+  }
+  return ordw;
+}
+
+// v8 shape_rewards for one agent (v8_robust_ppo.py:171-220), float64, one rounding per
+// operation.  w = the agent's shaper bits (prev_x, prev_y, valid, stationary), me = its post-step
+// position word, env_rew = its env reward.  Returns the new shaper bits.
+__device__ __forceinline__ uint32_t v8_shape(const Params& p, const double* dist, uint32_t w, uint32_t me, uint32_t act,
+                                             double env_rew, double& out) {
+  if (env_rew > 0.0) {                            // goal touch: prev_* cleared, count 0 (v8:181-186)
+    out = 5.0;
+    return 0u;
+  }
+  const int x = aw_x(me), y = aw_y(me);
+  double r = 0.0;
+  const bool has = (w >> 26) & 1u;
+  const int px = (int)((w >> 14) & 63u), py = (int)((w >> 20) & 63u);
+  uint32_t stat = (w >> 27) & 7u;
+  const double cur = dist[y * p.W + x];           // np.linalg.norm(pos - goal), v8:192
+  if (has) {
+    const double prev = dist[min(py, p.H - 1) * p.W + min(px, p.W - 1)];
+    r = r + (prev - cur) * 0.2;                   // v8:193-195
+    if (px == x && py == y) {                     // v8:199-206
+      stat = min(stat + 1u, 7u);                  // only "> 3" is ever tested: saturating is exact
+      if (stat > 3u) r = r - 0.05;
+    } else {
+      stat = 0u;
+      r = r + 0.02;
+    }
+  }
+  if (act == 2u) r = r + 0.02;                    // v8:209-212
+  else if (act <= 1u) r = r + 0.01;
+  if (-0.2 > r) r = -0.2;                         // max(reward, -0.2), v8:215
+  out = r;
+  return ((uint32_t)x << 14) | ((uint32_t)y << 20) | (1u << 26) | (stat << 27);   // v8:218
+}
+
 // One chunk (64 envs) of one step()/reset().
 template <int A, int V, bool TAB, bool FAST>
 __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, const double* dist, const uint32_t* table,
@@ -400,51 +501,14 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
   const uint32_t* const inj_spawn = FAST ? nullptr : p.reset_spawn;
   if (is_step) {
     // ---- actions -------------------------------------------------------------------------
-    if (!FAST && p.random_actions) {
-      const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), (uint32_t)P_ACTION << 28, p.seed_lo, p.seed_hi);
-      const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
-      actw = 0;
-#pragma unroll
-      for (int a = 0; a < A; ++a) actw |= __umulhi(rr[a & 3], 7u) << (3 * a);
-      if (p.actions_out && active) {
-        uint32_t w = 0;
-#pragma unroll
-        for (int a = 0; a < A; ++a) w |= ((actw >> (3 * a)) & 7u) << (8 * a);
-        p.actions_out[n] = w;
-      }
-    }
+    if (!FAST && p.random_actions) actw = draw_actions<A>(p, n, gid, active);
     // ---- step_count += 1 (multigrid.py:968) ----------------------------------------------
     uint32_t step = (st & 0xFFFFu) + 1u;
     uint32_t dbits = st >> 16;
     if (step > 0xFFFFu) step = 0xFFFFu;
 
     // ---- agent order (multigrid.py:973-974), packed 2 bits per slot --------------------------
-    uint32_t ordw = 0;
-#pragma unroll
-    for (int k = 0; k < A; ++k) ordw |= (uint32_t)k << (2 * k);
-    if (!FAST && p.order) {
-      uint32_t seen = 0, w = 0;
-      const uint32_t ow = p.order[n];
-#pragma unroll
-      for (int k = 0; k < A; ++k) {
-        const uint32_t o = (ow >> (8 * k)) & 255u;
-        if (o < (uint32_t)A) seen |= 1u << o;
-        w |= (o & 3u) << (2 * k);
-      }
-      if (seen != (1u << A) - 1u) { if (active) err |= MG_ERR_BAD_ORDER; }
-      else ordw = w;
-    } else if (A > 1 && MG_ABL != 3) {
-      const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), (uint32_t)P_ORDER << 28, p.seed_lo, p.seed_hi);
-      const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
-      // Fisher-Yates from the top, as np.random.shuffle does: swap slots i and j = rand(i+1)
-#pragma unroll
-      for (int i = A - 1, w = 0; i >= 1; --i, ++w) {
-        const uint32_t j = __umulhi(rr[w & 3], (uint32_t)(i + 1));
-        const uint32_t oi = (ordw >> (2 * i)) & 3u, oj = (ordw >> (2 * j)) & 3u;
-        ordw = (ordw & ~(3u << (2 * i)) & ~(3u << (2 * j))) | (oi << (2 * j));
-        ordw = (ordw & ~(3u << (2 * i))) | (oj << (2 * i));
-      }
-    }
+    const uint32_t ordw = agent_order<A, FAST>(p, n, gid, active, err);
 
     // ---- step_one_agent in that order (multigrid.py:860-924), branch-free except respawn -----
     uint32_t gbits = 0;          // agents whose forward touched the goal this step
@@ -488,37 +552,8 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
     for (int a = 0; a < A; ++a) {
       rew[a] = ((gbits >> a) & 1u) ? rgoal : 0.0;
       out_rew[a] = rew[a];
-      if (p.shaping == MG_SHAPING_V8 && MG_ABL != 4) {
-        const uint32_t w = shw[a], me = pd_get(pd, a), act = (actw >> (3 * a)) & 7u;
-        const int x = aw_x(me), y = aw_y(me);
-        uint32_t nw = 0;                              // goal touch: prev_* cleared, count 0 (v8:181-186)
-        if (rew[a] > 0.0) {
-          out_rew[a] = 5.0;
-        } else {
-          double r = 0.0;
-          const bool has = (w >> 26) & 1u;
-          const int px = (int)((w >> 14) & 63u), py = (int)((w >> 20) & 63u);
-          uint32_t stat = (w >> 27) & 7u;
-          const double cur = dist[y * p.W + x];       // np.linalg.norm(pos - goal), v8:192
-          if (has) {
-            const double prev = dist[min(py, p.H - 1) * p.W + min(px, p.W - 1)];
-            r = r + (prev - cur) * 0.2;               // v8:193-195
-            if (px == x && py == y) {                 // v8:199-206
-              stat = min(stat + 1u, 7u);              // only "> 3" is ever tested: saturating is exact
-              if (stat > 3u) r = r - 0.05;
-            } else {
-              stat = 0u;
-              r = r + 0.02;
-            }
-          }
-          if (act == 2u) r = r + 0.02;                // v8:209-212
-          else if (act <= 1u) r = r + 0.01;
-          if (-0.2 > r) r = -0.2;                     // max(reward, -0.2), v8:215
-          out_rew[a] = r;
-          nw = ((uint32_t)x << 14) | ((uint32_t)y << 20) | (1u << 26) | (stat << 27);   // v8:218
-        }
-        shw[a] = nw;
-      }
+      if (p.shaping == MG_SHAPING_V8 && MG_ABL != 4)
+        shw[a] = v8_shape(p, dist, shw[a], pd_get(pd, a), (actw >> (3 * a)) & 7u, rew[a], out_rew[a]);
     }
 
     st = step | (dbits << 16);
@@ -653,6 +688,8 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
   if (err) atomicOr(p.err, err);
 }
 
+#include "mg_dyn.h"
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -677,6 +714,13 @@ struct Variant { int A, V; kernel_fn generic[2], table[2]; int entw; };
 const Variant kVariants[] = {
     MG_VARIANT_TAB(1, 5), MG_VARIANT_TAB(2, 5), MG_VARIANT_TAB(3, 5), MG_VARIANT_TAB(4, 5), MG_VARIANT_TAB(3, 3),
     MG_VARIANT_GEN(1, 7), MG_VARIANT_GEN(2, 7), MG_VARIANT_GEN(3, 7),
+};
+
+// mutable-grid kernel instantiations
+struct DynVariant { int A, V; kernel_fn fn; };
+const DynVariant kDynVariants[] = {
+    {1, 7, mg_dyn_kernel<1, 7>}, {2, 7, mg_dyn_kernel<2, 7>}, {3, 7, mg_dyn_kernel<3, 7>},
+    {1, 5, mg_dyn_kernel<1, 5>}, {2, 5, mg_dyn_kernel<2, 5>}, {3, 5, mg_dyn_kernel<3, 5>},
 };
 
 // Host twin of static_view<V>: the static view of (x, y, dir) as a table entry
@@ -750,6 +794,13 @@ struct mg_handle {
   uint32_t* view_table;
   uint16_t* cell_index;
   uint32_t* err;
+  // mutable-grid path (DoorKey, layouts with objects)
+  bool dynamic;
+  const DynVariant* dvar;
+  int GW;
+  uint32_t* base_grid;
+  uint32_t* carry;
+  uint32_t* grid;
   mg_buffers buf;
   std::vector<void*> allocs;
 };
@@ -804,8 +855,27 @@ void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid
   *lds_out = lds;
 }
 
+// Mutable-grid launch geometry: 4 waves per workgroup (fewer for small batches), as many workgroups
+// per CU as LDS allows; persistent over chunks.
+void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* lds_out) {
+  const mg_config& c = h->cfg;
+  const size_t rowb = (size_t)c.view_size * c.view_size * 3;
+  const size_t fixed = ((size_t)c.width * c.height * 8 + 256 * 4 + (size_t)h->GW * 4 + 15) / 16 * 16;
+  const size_t per_wave = (size_t)kWave * rowb + (size_t)h->GW * kWave * 4;
+  int nw = 4;
+  while (nw > 1 && (fixed + nw * per_wave > (size_t)kLdsLimit || h->n_chunks < (int64_t)h->n_cu * nw)) nw >>= 1;
+  const size_t lds = fixed + nw * per_wave;
+  int per_cu = (int)((size_t)kLdsLimit / lds);
+  per_cu = std::max(1, std::min(per_cu, 32 / nw));
+  const int64_t blocks = (h->n_chunks + nw - 1) / nw;
+  *nw_out = nw;
+  *grid_out = (unsigned)std::min<int64_t>(blocks, (int64_t)h->n_cu * per_cu);
+  *lds_out = lds;
+}
+
 int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, const int8_t* respawn,
-           const int8_t* reset_spawn, const uint8_t* mask, int random_actions, uint8_t* actions_out) {
+           const int8_t* reset_spawn, const uint8_t* mask, int random_actions, uint8_t* actions_out,
+           const int8_t* objdrop = nullptr, const int8_t* reset_gen = nullptr) {
   Params p;
   memset(&p, 0, sizeof(p));
   const mg_config& c = h->cfg;
@@ -825,13 +895,59 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   p.mask = mask; p.actions_out = reinterpret_cast<uint32_t*>(actions_out);
   p.obs_image = h->buf.obs_image; p.reward = h->buf.reward;
   p.env_reward = h->buf.env_reward; p.dir_done = h->buf.dir_done; p.env_state = h->buf.env_state; p.err = h->err;
+  p.kind = c.env_kind; p.GW = h->GW; p.base_grid = h->base_grid;
+  p.objdrop = reinterpret_cast<const uint32_t*>(objdrop);
+  p.reset_gen = reinterpret_cast<const uint32_t*>(reset_gen);
+  p.carry = h->carry; p.grid = h->grid;
   int nw; unsigned grid; size_t lds;
-  launch_geometry(h, h->use_table, &nw, &grid, &lds);
   DeviceGuard g(h->device);
   if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
+  if (h->dynamic) {
+    dyn_geometry(h, &nw, &grid, &lds);
+    hipLaunchKernelGGL(h->dvar->fn, dim3(grid), dim3(nw * kWave), lds, h->stream, p);
+    HIP_TRY(hipGetLastError());
+    return MG_OK;
+  }
+  if (objdrop || reset_gen) return fail(MG_EINVAL, "objdrop / gen injection needs a mutable-grid handle");
+  launch_geometry(h, h->use_table, &nw, &grid, &lds);
   const int fast = (op == OP_STEP && !order && !respawn && !reset_spawn && !random_actions && !h->buf.env_reward) ? 1 : 0;
   hipLaunchKernelGGL(h->use_table ? h->var->table[fast] : h->var->generic[fast], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
   HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+
+// Switch the handle to the mutable-grid kernel: allocate the per-env grids and carry words (once),
+// upload the base layout every reset starts from and the shaper's distance LUT for goal (gx, gy).
+int enable_dynamic(mg_handle* h, const std::vector<uint8_t>& kinds, int gx, int gy) {
+  const mg_config& c = h->cfg;
+  if (!h->dvar) return fail(MG_EUNSUPPORTED, "no mutable-grid kernel instantiated for this (n_agents, view_size)");
+  DeviceGuard g(h->device);
+  if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
+  int nw; unsigned grid; size_t lds;
+  dyn_geometry(h, &nw, &grid, &lds);
+  if (lds > (size_t)kLdsLimit) return fail(MG_EUNSUPPORTED, "grid too large for the mutable-grid kernel's LDS budget");
+  int rc = MG_OK;
+  if (!h->grid) {
+    if (rc == MG_OK) rc = dalloc(h, &h->base_grid, (size_t)h->GW);
+    if (rc == MG_OK) rc = dalloc(h, &h->carry, (size_t)h->stride);
+    if (rc == MG_OK) rc = dalloc(h, &h->grid, (size_t)h->n_chunks * h->GW * kWave);
+    if (rc != MG_OK) return rc;
+  }
+  std::vector<uint32_t> base((size_t)h->GW, 0u);
+  for (size_t i = 0; i < kinds.size(); ++i) base[i >> 2] |= (uint32_t)kinds[i] << (8 * (i & 3));
+  std::vector<double> d((size_t)c.width * c.height);
+  for (int y = 0; y < c.height; ++y)
+    for (int x = 0; x < c.width; ++x) {
+      const long dx = x - gx, dy = y - gy;
+      d[(size_t)y * c.width + x] = sqrt((double)(dx * dx + dy * dy));   // np.linalg.norm (v8:192)
+    }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(h->base_grid, base.data(), base.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->dist_lut, d.data(), d.size() * 8, hipMemcpyHostToDevice));
+  h->gx = gx; h->gy = gy;
+  h->dynamic = true; h->use_table = false; h->n_entries = 0;
+  h->have_map = true;
+  h->buf.carry = h->carry; h->buf.grid = h->grid; h->buf.grid_words = h->GW; h->buf.mutable_grid = 1;
   return MG_OK;
 }
 
@@ -840,7 +956,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
 extern "C" {
 
 const char* mg_last_error(void) { return g_err.c_str(); }
-const char* mg_version(void) { return "mgrid-hip 0.2 (gfx950)"; }
+const char* mg_version(void) { return "mgrid-hip 0.3 (gfx950)"; }
 
 int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (!cfg || !out) return fail(MG_EINVAL, "null argument");
@@ -853,11 +969,22 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (c.kernel_path < MG_PATH_AUTO || c.kernel_path > MG_PATH_TABLE) return fail(MG_EINVAL, "unknown kernel_path");
   if (c.env_id_base < 0 || (uint64_t)c.env_id_base + (uint64_t)c.n_envs > 0xFFFFFFFFull)
     return fail(MG_EINVAL, "global env ids must fit 32 bits");
+  if (c.env_kind != MG_KIND_STATIC && c.env_kind != MG_KIND_DOORKEY) return fail(MG_EINVAL, "unknown env_kind");
   const Variant* var = nullptr;
   for (const Variant& v : kVariants)
     if (v.A == c.n_agents && v.V == c.view_size) var = &v;
-  if (!var) return fail(MG_EUNSUPPORTED, "no kernel instantiated for this (n_agents, view_size)");
-  if (c.kernel_path == MG_PATH_TABLE && !var->table[0]) return fail(MG_EUNSUPPORTED, "no table kernel for this view_size");
+  const DynVariant* dvar = nullptr;
+  for (const DynVariant& v : kDynVariants)
+    if (v.A == c.n_agents && v.V == c.view_size) dvar = &v;
+  if (c.env_kind == MG_KIND_STATIC) {
+    if (!var) return fail(MG_EUNSUPPORTED, "no kernel instantiated for this (n_agents, view_size)");
+    if (c.kernel_path == MG_PATH_TABLE && !var->table[0]) return fail(MG_EUNSUPPORTED, "no table kernel for this view_size");
+  } else {
+    if (!dvar) return fail(MG_EUNSUPPORTED, "no mutable-grid kernel instantiated for this (n_agents, view_size)");
+    if (c.width != c.height || c.width < 5) return fail(MG_EINVAL, "DoorKey needs a square grid of size >= 5");
+    if (c.kernel_path == MG_PATH_TABLE) return fail(MG_EUNSUPPORTED, "no table kernel for mutable grids");
+    var = nullptr;
+  }
 
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
@@ -867,6 +994,8 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
 
   mg_handle* h = new mg_handle();
   h->cfg = c; h->device = device; h->var = var; h->t = 0; h->have_map = h->have_reset = false;
+  h->dynamic = false; h->dvar = dvar; h->GW = (c.width * c.height + 3) / 4;
+  h->base_grid = nullptr; h->carry = nullptr; h->grid = nullptr;
   h->use_table = false; h->n_entries = 0; h->view_table = nullptr; h->cell_index = nullptr;
   h->stride = (c.n_envs + 63) / 64 * 64;
   h->n_chunks = h->stride / 64;
@@ -881,7 +1010,8 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   h->own_stream = true;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail(MG_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
-  for (kernel_fn fn : {var->generic[0], var->generic[1], var->table[0], var->table[1]}) {
+  for (kernel_fn fn : {var ? var->generic[0] : nullptr, var ? var->generic[1] : nullptr, var ? var->table[0] : nullptr,
+                       var ? var->table[1] : nullptr, dvar ? dvar->fn : nullptr}) {
     if (!fn) continue;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
     if (e != hipSuccess) { (void)hipStreamDestroy(h->stream); delete h; return fail(MG_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
@@ -893,7 +1023,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (rc == MG_OK) rc = dalloc(h, &h->map_pad, (size_t)h->PW * h->PH);
   if (rc == MG_OK) rc = dalloc(h, &h->dist_lut, (size_t)c.width * c.height);
   if (rc == MG_OK) rc = dalloc(h, &h->cell_index, (size_t)c.width * c.height);
-  if (rc == MG_OK) rc = dalloc(h, &h->view_table, (size_t)c.width * c.height * 4 * (var->entw ? var->entw : 4));
+  if (rc == MG_OK && var) rc = dalloc(h, &h->view_table, (size_t)c.width * c.height * 4 * (var->entw ? var->entw : 4));
   if (rc == MG_OK) rc = dalloc(h, &h->err, 1);
   if (rc == MG_OK) rc = dalloc(h, &h->buf.obs_image, A * S * rowb);
   if (rc == MG_OK) rc = dalloc(h, &h->buf.reward, A * S);
@@ -908,6 +1038,17 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   }
   h->buf.n_envs = c.n_envs; h->buf.env_stride = h->stride; h->buf.n_agents = c.n_agents; h->buf.obs_cell_bytes = rowb;
   h->buf.dir_done_bytes = h->dd_bytes;
+  if (c.env_kind == MG_KIND_DOORKEY) {
+    // the part of DoorKeyEnv._gen_grid that is the same for every env and every reset
+    // (doorkey.py:38-44): border walls and the goal at (W-2, H-2); the rest is drawn on device
+    std::vector<uint8_t> kinds((size_t)c.width * c.height, 0);
+    for (int y = 0; y < c.height; ++y)
+      for (int x = 0; x < c.width; ++x)
+        if (x == 0 || y == 0 || x == c.width - 1 || y == c.height - 1) kinds[(size_t)y * c.width + x] = (uint8_t)K_WALL;
+    kinds[(size_t)(c.height - 2) * c.width + (c.width - 2)] = (uint8_t)K_GOAL;
+    rc = enable_dynamic(h, kinds, c.width - 2, c.height - 2);
+    if (rc != MG_OK) { mg_destroy(h); return rc; }
+  }
   *out = h;
   return MG_OK;
 }
@@ -925,7 +1066,37 @@ int mg_destroy(mg_handle* h) {
 int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
   if (!h || !cells) return fail(MG_EINVAL, "null argument");
   const mg_config& cfg = h->cfg;
+  if (cfg.env_kind != MG_KIND_STATIC) return fail(MG_EINVAL, "this env_kind generates its own grids; no static map");
   const int W = cfg.width, H = cfg.height, V = cfg.view_size, pad = V - 1;
+  {
+    // any object an agent can pick up, toggle or walk onto and destroy -> per-env mutable grids
+    bool objects = false;
+    std::vector<uint8_t> kinds((size_t)W * H, 0);
+    int n_free = 0, gx = -1, gy = -1;
+    for (int i = 0; i < W * H; ++i) {
+      const uint8_t* c = cells + (size_t)i * 3;
+      switch (c[0]) {
+        case MG_T_UNSEEN: case MG_T_EMPTY: ++n_free; break;
+        case MG_T_WALL: case MG_T_GOAL: case MG_T_LAVA: kinds[i] = (uint8_t)(c[0] * 8 + (c[1] & 7)); break;
+        case MG_T_FLOOR: case MG_T_KEY: case MG_T_BALL: case MG_T_BOX:
+          kinds[i] = (uint8_t)(c[0] * 8 + (c[1] & 7)); objects = true; break;
+        case MG_T_DOOR:
+          if (c[2] > 2) return fail(MG_EINVAL, "door state must be 0 (open), 1 (closed) or 2 (locked)");
+          kinds[i] = (uint8_t)(128 + (c[1] & 7) * 4 + c[2]); objects = true; break;
+        default: return fail(MG_EUNSUPPORTED, "unknown object type in the map");
+      }
+    }
+    if (objects) {
+      if (n_free < cfg.n_agents) return fail(MG_EINVAL, "fewer free cells than agents");
+      for (int i = 0; i < W && gx < 0; ++i)      // get_goal_position (v8_robust_ppo.py:159-169)
+        for (int j = 0; j < H; ++j)
+          if (cells[((size_t)j * W + i) * 3] == MG_T_GOAL) { gx = i; gy = j; break; }
+      if (gx < 0) { gx = 13; gy = 13; }
+      return enable_dynamic(h, kinds, gx, gy);
+    }
+    h->dynamic = false;
+    h->buf.carry = nullptr; h->buf.grid = nullptr; h->buf.grid_words = 0; h->buf.mutable_grid = 0;
+  }
   const uint32_t wall = (uint32_t)MG_T_WALL | (5u << 8) | F_OPAQUE;   // Grid.slice's out-of-bounds Wall() (multigrid.py:315)
   std::vector<uint32_t> m((size_t)h->PW * h->PH, wall);
   std::vector<uint16_t> cidx((size_t)W * H, 0);
@@ -935,7 +1106,7 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
       const uint8_t* c = cells + ((size_t)y * W + x) * 3;
       uint32_t w = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
       switch (c[0]) {
-        case MG_T_EMPTY: w = (uint32_t)MG_T_EMPTY | F_FREE; cidx[(size_t)y * W + x] = (uint16_t)n_free++; break;
+        case MG_T_UNSEEN: case MG_T_EMPTY: w = (uint32_t)MG_T_EMPTY | F_FREE; cidx[(size_t)y * W + x] = (uint16_t)n_free++; break;
         case MG_T_WALL: w |= F_OPAQUE; break;
         case MG_T_GOAL: w |= F_KILL | F_GOAL; break;
         case MG_T_LAVA: w |= F_KILL; break;
@@ -1031,6 +1202,38 @@ int mg_step_replay(mg_handle* h, const void* actions, const uint8_t* order, cons
   return rc;
 }
 
+int mg_reset_inject_dyn(mg_handle* h, const uint8_t* env_mask, const int8_t* spawn, const int8_t* gen) {
+  if (!h) return fail(MG_EINVAL, "null handle");
+  if (!h->have_map) return fail(MG_ESTATE, "mg_set_static_map must be called before mg_reset_inject_dyn");
+  if (!h->dynamic) return fail(MG_EINVAL, "not a mutable-grid handle");
+  int rc = launch(h, OP_RESET, nullptr, nullptr, nullptr, spawn, env_mask, 0, nullptr, nullptr, gen);
+  if (rc == MG_OK) h->have_reset = true;
+  return rc;
+}
+
+int mg_step_replay_dyn(mg_handle* h, const void* actions, const uint8_t* order, const int8_t* respawn,
+                       const int8_t* objdrop, const int8_t* reset_spawn, const int8_t* reset_gen) {
+  if (!h || !actions) return fail(MG_EINVAL, "null argument");
+  if (!h->dynamic) return fail(MG_EINVAL, "not a mutable-grid handle");
+  if (!h->have_reset) return fail(MG_ESTATE, "mg_reset must be called before mg_step_replay_dyn");
+  int rc = launch(h, OP_STEP, actions, order, respawn, reset_spawn, nullptr, 0, nullptr, objdrop, reset_gen);
+  if (rc == MG_OK) h->t += 1;
+  return rc;
+}
+
+int mg_export_grid(mg_handle* h, uint8_t* out) {
+  if (!h || !out) return fail(MG_EINVAL, "null argument");
+  if (!h->dynamic) return fail(MG_EINVAL, "not a mutable-grid handle");
+  DeviceGuard g(h->device);
+  if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
+  const int cells = h->cfg.width * h->cfg.height;
+  const int64_t total = h->cfg.n_envs * cells;
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65536);
+  hipLaunchKernelGGL(export_grid_kernel, dim3(blocks), dim3(256), 0, h->stream, h->grid, h->GW, cells, h->cfg.n_envs, out);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+
 int mg_step_random(mg_handle* h, uint8_t* actions_out) {
   if (!h) return fail(MG_EINVAL, "null handle");
   if (!h->have_reset) return fail(MG_ESTATE, "mg_reset must be called before mg_step_random");
@@ -1098,7 +1301,8 @@ int mg_get_goal(mg_handle* h, int32_t* gx, int32_t* gy) {
 int mg_get_launch_info(mg_handle* h, int32_t* path, int32_t* block_threads, int32_t* grid_blocks, int32_t* lds_bytes) {
   if (!h) return fail(MG_EINVAL, "null handle");
   int nw; unsigned grid; size_t lds;
-  launch_geometry(h, h->use_table, &nw, &grid, &lds);
+  if (h->dynamic) dyn_geometry(h, &nw, &grid, &lds);
+  else launch_geometry(h, h->use_table, &nw, &grid, &lds);
   if (path) *path = h->use_table ? MG_PATH_TABLE : MG_PATH_GENERIC;
   if (block_threads) *block_threads = nw * kWave;
   if (grid_blocks) *grid_blocks = (int32_t)grid;

@@ -9,13 +9,23 @@ MG_OK = 0
 SHAPING_NONE, SHAPING_V8 = 0, 1
 PATH_AUTO, PATH_GENERIC, PATH_TABLE = 0, 1, 2
 ERR_BAD_ACTION, ERR_BAD_RESPAWN, ERR_BAD_ORDER, ERR_MISSING_DRAW = 1, 2, 4, 8
+KIND_STATIC, KIND_DOORKEY = 0, 1
+
+
+def kind_id(type_, color=0, state=0):
+  """MG_KIND_ID (include/mgrid.h): one-byte cell kind of the mutable per-env grids."""
+  if type_ in (0, 1, 10):
+    return 0
+  if type_ == 4:
+    return 128 + color * 4 + state
+  return type_ * 8 + color
 
 
 class MgConfig(C.Structure):
   _fields_ = [
       ('width', C.c_int32), ('height', C.c_int32), ('n_agents', C.c_int32), ('view_size', C.c_int32),
       ('max_steps', C.c_int32), ('see_through_walls', C.c_int32), ('competitive', C.c_int32),
-      ('shaping_kind', C.c_int32), ('auto_reset', C.c_int32), ('reserved0', C.c_int32),
+      ('shaping_kind', C.c_int32), ('auto_reset', C.c_int32), ('env_kind', C.c_int32),
       ('emit_env_reward', C.c_int32), ('kernel_path', C.c_int32),
       ('n_envs', C.c_int64), ('env_id_base', C.c_int64), ('seed', C.c_uint64),
   ]
@@ -26,6 +36,7 @@ class MgBuffers(C.Structure):
       ('n_envs', C.c_int64), ('env_stride', C.c_int64), ('n_agents', C.c_int32), ('obs_cell_bytes', C.c_int32),
       ('obs_image', C.c_void_p), ('reward', C.c_void_p), ('env_reward', C.c_void_p), ('dir_done', C.c_void_p),
       ('dir_done_bytes', C.c_int32), ('reserved', C.c_int32), ('env_state', C.c_void_p),
+      ('carry', C.c_void_p), ('grid', C.c_void_p), ('grid_words', C.c_int32), ('mutable_grid', C.c_int32),
   ]
 
 
@@ -38,6 +49,9 @@ SYMBOLS = {
     'mg_reset_inject': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'mg_step': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_step_replay': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mg_reset_inject_dyn': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mg_step_replay_dyn': (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
+    'mg_export_grid': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_step_random': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_get_buffers': (C.c_int, [C.c_void_p, C.POINTER(MgBuffers)]),
     'mg_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),

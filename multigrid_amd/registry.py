@@ -30,12 +30,21 @@ register('MultiGrid-Cluttered-Fixed-15x15', dict(
     layout=layouts.cluttered_fixed_15x15, n_agents=3, view_size=5, max_steps=100,
     see_through_walls=False, competitive=False))
 
+# DoorKeyEnv family (multigrid_envs/doorkey.py:27-161): view 7 (multigrid.py:333 default),
+# max_steps 10*size^2, layouts drawn per env and per reset on device.  The 16x16 five-agent id is
+# not registered: the kernels pack at most four agents.
+for _id, _size, _agents in (('MultiGrid-DoorKey-6x6-v0', 6, 2), ('MultiGrid-DoorKey-8x8-v0', 8, 3),
+                            ('MultiGrid-DoorKey-5x5-Single-v0', 5, 1), ('MultiGrid-DoorKey-6x6-Single-v0', 6, 1),
+                            ('MultiGrid-DoorKey-8x8-Single-v0', 8, 1), ('MultiGrid-DoorKey-16x16-Single-v0', 16, 1)):
+  register(_id, dict(kind='doorkey', size=_size, n_agents=_agents, view_size=7, max_steps=10 * _size * _size,
+                     see_through_walls=False, competitive=False))
+
 
 def make_batched(env_id, n_envs, **kw):
   """N device-resident envs of `env_id` (BatchedMultiGrid)."""
   from .batched import BatchedMultiGrid
   s = spec(env_id)
-  cells = s.pop('layout')()
+  cells = s.pop('layout')() if 'layout' in s else None
   s.update(kw)
   return BatchedMultiGrid(cells, n_envs=n_envs, **s)
 

@@ -1,0 +1,238 @@
+"""GPU parity of the mutable-grid kernel (BASELINE config 4): DoorKey and fixed
+layouts holding keys / balls / boxes / doors / floor, through the C ABI against the CPU oracle,
+bit for bit: obs, direction, rewards, done, agent / step state, carried objects, every env's grid.
+
+Parity status: unpinned (no DoorKey fixture in the reference; see tests/test_oracle_doorkey.py for
+what anchors the oracle).
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle  # noqa: E402
+
+
+def _need_gpu():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+
+
+def _cmp(env, orc, what, step=True):
+  n, A = env.n_envs, env.n_agents
+  assert np.array_equal(env.agent_state.cpu().numpy().view(np.uint32), orc.agent_state()[:, :n]), what + ' agent_state'
+  assert np.array_equal(env.step_state.cpu().numpy().view(np.uint32), orc.step_state()[:n]), what + ' step_state'
+  carry, kinds = orc.dyn_state()
+  assert np.array_equal(env.carry.cpu().numpy().view(np.uint32), carry[:n]), what + ' carry'
+  assert np.array_equal(env.grid_kinds().cpu().numpy(), kinds[:n]), what + ' grid'
+  assert np.array_equal(env.obs_image.cpu().numpy().reshape(A, n, -1), orc.obs_image[:, :n]), what + ' obs_image'
+  assert np.array_equal(env.obs_dir.cpu().numpy(), orc.obs_dir[:, :n]), what + ' obs_dir'
+  if step:
+    assert np.array_equal(env.reward.cpu().numpy().view(np.int64), orc.reward[:, :n].view(np.int64)), what + ' reward'
+    assert np.array_equal(env.env_reward.cpu().numpy().view(np.int64), orc.env_reward[:, :n].view(np.int64)), what + ' env_reward'
+    assert np.array_equal(env.done.cpu().numpy(), orc.done[:n]), what + ' done'
+
+
+def _doorkey(size, A, n, max_steps, seed, shaping='v8', **kw):
+  from multigrid_amd.batched import BatchedMultiGrid
+  env = BatchedMultiGrid(None, n_envs=n, kind='doorkey', size=size, n_agents=A, view_size=7, max_steps=max_steps,
+                         shaping=shaping, seed=seed, emit_env_reward=True, **kw)
+  orc = c_oracle.OracleBatch(None, n, W=size, H=size, A=A, V=7, max_steps=max_steps, shaping=1 if shaping == 'v8' else 0,
+                             auto_reset=int(kw.get('auto_reset', True)), competitive=int(kw.get('competitive', False)),
+                             seed=seed, gid_base=kw.get('env_id_base', 0), kind='doorkey')
+  return env, orc
+
+
+def _events(orc, prev_carry):
+  carry, kinds = orc.dyn_state()
+  n = orc.n
+  ev = dict(pickup=int(((prev_carry[:n] == 0) & (carry[:n] != 0)).sum()),
+            open_doors=int(((kinds[:n] >= 128) & ((kinds[:n] & 3) == 0)).sum()),
+            no_door=int((~(kinds[:n] >= 128).any(axis=(1, 2))).sum()))
+  return ev, carry
+
+
+@pytest.mark.parametrize('size,A,n,steps,max_steps', [(5, 1, 1500, 220, 60), (6, 2, 1000, 220, 70),
+                                                      (8, 3, 4096, 260, 90), (16, 1, 300, 120, 50)])
+def test_doorkey_free_running_parity(size, A, n, steps, max_steps):
+  """Generator, order, respawn, re-placed objects and actions all drawn by Philox on both sides;
+  short episodes so that the auto-reset (a fresh layout per env) fires several times."""
+  _need_gpu()
+  env, orc = _doorkey(size, A, n, max_steps, seed=size * 10 + A, env_id_base=1000)
+  assert env.mutable_grid and env.launch_info()['path'] == 'generic'
+  env.reset()
+  orc.reset()
+  _cmp(env, orc, 'reset', step=False)
+  tot = dict(pickup=0, open_doors=0, no_door=0, goal=0, objdrop=0)
+  prev = orc.dyn_state()[0]
+  for t in range(steps):
+    env.step_random()
+    orc.step()
+    _cmp(env, orc, 'step %d' % t)
+    ev, prev = _events(orc, prev)
+    for k, v in ev.items():
+      tot[k] += v
+    tot['goal'] += int((orc.env_reward[:, :n] > 0).sum())
+    tot['objdrop'] += int((orc.last_gen()[1][:, :n, 0] >= 0).sum()) if t % 16 == 0 else 0
+  assert env.check_errors() == 0 and orc.errors() == 0
+  if size <= 8:
+    assert tot['pickup'] > 0 and tot['open_doors'] > 0, tot
+  if size == 5:
+    assert tot['goal'] > 0 and tot['no_door'] > 0, tot
+  env.close()
+
+
+def test_doorkey_actions_from_host_and_explicit_reset():
+  """mg_step with uploaded actions (biased towards the useful ones), auto_reset off: masked resets
+  driven by the caller, as the reference's training loops do."""
+  _need_gpu()
+  n, A, size = 2000, 3, 8
+  env, orc = _doorkey(size, A, n, 40, seed=5, auto_reset=False)
+  rng = np.random.RandomState(5)
+  env.reset()
+  orc.reset()
+  for t in range(130):
+    act = rng.choice(7, size=(A, orc.stride), p=[.14, .14, .3, .14, .06, .16, .06]).astype(np.uint8)
+    env.step(torch.from_numpy(act).to(env.device))
+    orc.step(act)
+    _cmp(env, orc, 'step %d' % t)
+    done = orc.done.copy()
+    if done[:n].any():
+      env.reset(mask=torch.from_numpy(done[:n]).to(env.device))
+      orc.reset(mask=done)
+      _cmp(env, orc, 'masked reset %d' % t, step=False)
+  assert env.check_errors() == 0
+  env.close()
+
+
+def test_doorkey_replay_injection():
+  """Bit-exact replay: every draw an oracle run (seed X) recorded — layout, spawn, order, respawn,
+  re-placed object — injected into a device run keyed with a different seed."""
+  _need_gpu()
+  n, A, size = 3000, 2, 6
+  from multigrid_amd.batched import BatchedMultiGrid
+  env = BatchedMultiGrid(None, n_envs=n, kind='doorkey', size=size, n_agents=A, view_size=7, max_steps=50,
+                         shaping='v8', seed=999, emit_env_reward=True)
+  orc = c_oracle.OracleBatch(None, n, W=size, H=size, A=A, V=7, max_steps=50, shaping=1, auto_reset=1, seed=123,
+                             kind='doorkey')
+  rng = np.random.RandomState(9)
+  orc.reset()
+  gen, _ = orc.last_gen()
+  _, _, spawn = orc.last_draws()
+  env.reset(spawn=spawn, gen=gen)
+  _cmp(env, orc, 'reset', step=False)
+  drops = 0
+  for t in range(200):
+    act = rng.choice(7, size=(A, orc.stride), p=[.12, .12, .34, .14, .06, .16, .06]).astype(np.uint8)
+    orc.step(act)
+    order, respawn, rspawn = orc.last_draws()
+    rgen, objdrop = orc.last_gen()
+    drops += int((objdrop[:, :n, 0] >= 0).sum())
+    env.step_replay(torch.from_numpy(act), order, respawn, reset_spawn=rspawn, objdrop=objdrop, reset_gen=rgen)
+    _cmp(env, orc, 'replay step %d' % t)
+  assert env.check_errors() == 0
+  assert drops > 0          # an agent reached the goal with the key in hand
+  env.close()
+
+
+def test_doorkey_bad_injection_is_reported():
+  _need_gpu()
+  from multigrid_amd import lib
+  n = 64
+  env, orc = _doorkey(6, 2, n, 50, seed=1)
+  gen = np.zeros((n, 4), np.int8)
+  gen[:] = (3, 2, 1, 1)
+  spawn = np.zeros((2, n, 4), np.int8)
+  spawn[0, :, :3] = (1, 2, 0)
+  spawn[1, :, :3] = (2, 2, 1)
+  env.reset(spawn=spawn, gen=gen)
+  assert env.check_errors() == 0
+  gen[5] = (3, 2, 4, 1)        # key right of the wall: outside place_obj's rectangle
+  env.reset(spawn=spawn, gen=gen)
+  assert env.check_errors() == lib.ERR_BAD_RESPAWN
+  gen[5] = (9, 2, 1, 1)        # split outside the grid
+  env.reset(spawn=spawn, gen=gen)
+  assert env.check_errors() & lib.ERR_BAD_RESPAWN
+  spawn[1, 7, :3] = (1, 2, 0)  # two agents on one cell
+  gen[5] = (3, 2, 1, 1)
+  env.reset(spawn=spawn, gen=gen)
+  assert env.check_errors() == lib.ERR_BAD_RESPAWN
+  env.close()
+
+
+@pytest.mark.parametrize('A,V,n,seed', [(3, 5, 3000, 4), (2, 7, 1000, 8), (1, 5, 700, 2)])
+def test_object_playground_parity(playground_cells, A, V, n, seed):
+  """A fixed layout holding every object type: mg_set_static_map switches to per-env mutable grids."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  cells = playground_cells
+  H, W = cells.shape[:2]
+  env = BatchedMultiGrid(cells, n_envs=n, n_agents=A, view_size=V, max_steps=60, shaping='v8', seed=seed,
+                         emit_env_reward=True)
+  orc = c_oracle.OracleBatch(cells, n, W=W, H=H, A=A, V=V, max_steps=60, shaping=1, auto_reset=1, seed=seed)
+  assert env.mutable_grid and env.goal_pos == (7, 1)
+  env.reset()
+  orc.reset()
+  _cmp(env, orc, 'reset', step=False)
+  boxes0 = int((orc.dyn_state()[1][:n] >> 3 == 7).sum())
+  fewer_boxes = False
+  for t in range(200):
+    env.step_random()
+    orc.step()
+    _cmp(env, orc, 'step %d' % t)
+    if t % 20 == 0:
+      carry, kinds = orc.dyn_state()
+      held = sum(int((((carry[:n] >> 8 * a) & 255) >> 3 == 7).sum()) for a in range(A))
+      fewer_boxes = fewer_boxes or int(((kinds[:n] < 128) & (kinds[:n] >> 3 == 7)).sum()) + held < boxes0
+  assert env.check_errors() == 0 and orc.errors() == 0
+  assert fewer_boxes          # Box.toggle happened somewhere
+  env.close()
+
+
+def test_static_map_switches_back_to_shared_kernel(cluttered_cells):
+  """A handle that ran a layout with objects keeps working when given an object-free one again."""
+  _need_gpu()
+  from multigrid_amd import lib as _lib
+  import ctypes as C
+  from multigrid_amd.batched import BatchedMultiGrid
+  from multigrid_amd import layouts
+  a = layouts.empty_bordered(15, 15, goal=(13, 13))
+  b = a.copy()
+  b[5, 5] = (5, 4, 0)
+  env = BatchedMultiGrid(b, n_envs=200, seed=3, emit_env_reward=True)
+  assert env.mutable_grid
+  env.reset()
+  env.step_random()
+  _lib.check(env.L.mg_set_static_map(env.h, np.ascontiguousarray(cluttered_cells).ctypes.data_as(C.c_void_p)))
+  orc = c_oracle.OracleBatch(cluttered_cells, 200, shaping=1, auto_reset=1, seed=3)
+  env.step_index = 0
+  env.reset()
+  orc.reset()
+  for t in range(30):
+    env.step_random()
+    orc.step()
+  n = 200
+  assert np.array_equal(env.obs_image.cpu().numpy().reshape(3, n, -1), orc.obs_image[:, :n])
+  assert np.array_equal(env.agent_state.cpu().numpy().view(np.uint32), orc.agent_state()[:, :n])
+  env.close()
+
+
+def test_doorkey_registry_and_refcompat():
+  """gym.make('MultiGrid-DoorKey-6x6-v0') counterpart: one env, the reference's list-of-arrays contract."""
+  _need_gpu()
+  import multigrid_amd
+  env = multigrid_amd.make('MultiGrid-DoorKey-6x6-v0', shaping=None, auto_reset=False, seed=17)
+  orc = c_oracle.OracleEnv(None, W=6, H=6, A=2, V=7, max_steps=360, kind='doorkey', seed=17, gid=0)
+  obs = env.reset()
+  oobs = orc.reset()
+  rng = np.random.RandomState(3)
+  for t in range(80):
+    for a in range(2):
+      assert np.array_equal(obs['image'][a], oobs['image'][a]) and obs['direction'][a] == oobs['direction'][a]
+    act = [int(v) for v in rng.randint(0, 7, size=2)]
+    obs, rew, done, _ = env.step(act)
+    oobs, orew, odone, _ = orc.step(act)
+    assert list(rew) == list(orew) and done == odone
+  env.close()
