@@ -138,10 +138,10 @@ typedef struct mg_buffers {
                             | (DOORKEY only) split_idx<<24, the width of the region agents (re)spawn in (doorkey.py:77-78) */
   /* mutable-grid handles only (mutable_grid != 0), NULL / 0 otherwise: */
   uint32_t* carry;       /* [env_stride]: byte a = kind id of the object agent a carries, 0 = nothing (multigrid.py:490, 926-951) */
-  uint32_t* grid;        /* [env_stride/64][grid_words][64]: dword j of env n at ((n/64)*grid_words + j)*64 + n%64;
-                            byte b of dword j = kind id of cell index 4j+b = y*W + x.  (One wavefront moves its 64 envs'
-                            grids between HBM and LDS as grid_words fully coalesced 256-byte rows; use mg_export_grid for a
-                            plain [n][H*W] copy.) */
+  uint32_t* grid;        /* bytes [env_stride/64][grid_words*4][64]: kind id of cell ci = y*W + x of env n at byte
+                            ((n/64)*grid_words*4 + ci)*64 + n%64 (cells >= W*H are padding).  Cell-major within a 64-env
+                            chunk, so a wavefront moves its chunk between HBM and LDS as fully coalesced rows and a lane's
+                            LDS address is linear in the cell index; use mg_export_grid for a plain [n][H*W] copy. */
   int32_t  grid_words;   /* ceil(W*H/4) */
   int32_t  mutable_grid;
 } mg_buffers;

@@ -88,7 +88,7 @@ class BatchedMultiGrid:
     if self.mutable_grid:
       self.grid_words = int(b.grid_words)
       self.carry = _alias(b.carry, (S,), '<i4', dev)[:n]                        # byte a = kind agent a carries
-      self.grid_blocked = _alias(b.grid, (S // 64, self.grid_words, 64, 4), '|u1', dev)   # layout in include/mgrid.h
+      self.grid_blocked = _alias(b.grid, (S // 64, self.grid_words * 4, 64), '|u1', dev)  # [chunk][cell][lane], include/mgrid.h
     # action buffer in the layout the kernel reads: one dword per env, byte a = agent a's action.
     # Policies write `env.actions[:N, a]`; `step()` with no argument consumes it.
     self.actions = torch.full((S, 4), 6, dtype=torch.uint8, device=dev)

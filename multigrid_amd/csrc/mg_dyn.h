@@ -4,11 +4,15 @@
 // shared-map kernel.
 //
 // Every env owns a W*H grid of one-byte kind ids (include/mgrid.h MG_KIND_ID) plus one "carry" word
-// (byte a = what agent a carries).  HBM keeps the grids chunk-blocked, [chunk][dword j][64 lanes],
-// so a wavefront moves its 64 envs' grids to and from LDS as GW fully coalesced 256-byte rows, and
-// in LDS lane l's dword j sits at bank (j*64 + l) % 64 = l: every per-lane byte access of the step
-// is conflict free whatever cell each env touches.  Agents are not stored in the grid; their cells
-// read 0 and they are overlaid from the packed position word, as on the shared-map path.
+// (byte a = what agent a carries).  HBM keeps the grids chunk-blocked and cell-major,
+// [chunk][cell y*W+x][64 lanes] bytes, so a wavefront moves its 64 envs' grids to and from LDS as
+// fully coalesced dword rows.  In LDS the wave's grids are padded by one ring of grey walls,
+// [(H+2)*(W+2) cells][68 bytes: 64 lanes + 4 pad]: a lane's byte address is LINEAR in the cell
+// coordinates (cell*68 + lane), so a view cell costs one add + one byte read, cells outside the
+// grid are reached by clamping the coordinate onto the ring (Grid.slice pads with the same grey
+// Wall, multigrid.py:315) and the 17-dword cell stride spreads the lanes' cells over the banks.
+// Agents are not stored in the grid; their cells read 0 and they are overlaid from the packed
+// position word, as on the shared-map path.
 //
 // Reference: envs/gym_multigrid/multigrid.py:815-961 (agent_is_done, move_agent, _forward, _pickup,
 // _drop, _toggle), :112-122 (Door.toggle), :997-1035 (gen_obs_grid with the carried object on the
@@ -48,15 +52,20 @@ __host__ __device__ inline uint32_t kind_word(uint32_t k) {
   return w;
 }
 
-// g = LDS byte address of this lane's dword 0; cell index ci = y*W + x
-__device__ __forceinline__ uint32_t g_get(const uint8_t* g, int ci) { return g[((ci >> 2) << 8) | (ci & 3)]; }
-__device__ __forceinline__ void g_set(uint8_t* g, int ci, uint32_t k) { g[((ci >> 2) << 8) | (ci & 3)] = (uint8_t)k; }
+// LDS grid of one wave: cell (x, y), x in [-1, W], y in [-1, H] (the ring holds grey walls), lane l
+// at byte ((y+1)*(W+2) + x+1)*kCellB + l.  gl = the wave's grid base + lane.
+constexpr int kCellB = 68;    // bytes per cell row: 64 lanes + 4 (bank spreading)
+constexpr int kCellW = 17;    // the same in dwords
+constexpr int kPreMax = 16;   // grid dwords per lane that are prefetched in registers (W*H <= 64)
+__device__ __forceinline__ int g_off(const Params& p, int x, int y) { return ((y + 1) * (p.W + 2) + x + 1) * kCellB; }
+__device__ __forceinline__ uint32_t g_get(const uint8_t* gl, int off) { return gl[off]; }
+__device__ __forceinline__ void g_set(uint8_t* gl, int off, uint32_t k) { gl[off] = (uint8_t)k; }
 
 // place_obj's acceptance test (multigrid.py:603-613) inside x < xmax on this env's own grid
 template <int A>
 __device__ __forceinline__ bool dyn_free(const Params& p, const uint8_t* g, uint64_t pd, uint32_t occ, int x, int y, int xmax) {
   if ((unsigned)x >= (unsigned)min(xmax, p.W) || (unsigned)y >= (unsigned)p.H) return false;
-  if (g_get(g, y * p.W + x) != 0u) return false;
+  if (g_get(g, g_off(p, x, y)) != 0u) return false;
   const uint32_t pos = (uint32_t)x | ((uint32_t)y << 6);
   bool ok = true;
 #pragma unroll
@@ -97,8 +106,10 @@ __device__ __forceinline__ uint32_t place_dyn(const Params& p, const uint8_t* g,
 }
 
 // gen_obs_grid (multigrid.py:997-1035) from this env's own grid: view cell (vx,vy) = world cell
-// pos + f*(V-1-vy) + r*(vx-V/2); cells outside the grid are Grid.slice's grey walls (:315); the own
-// cell shows the carried object (:1029-1033).
+// pos + f*(V-1-vy) + r*(vx-V/2); cells outside the grid are Grid.slice's grey walls (:315), reached
+// by clamping each coordinate onto the ring; the own cell shows the carried object (:1029-1033).
+// Exactly one of (r.x, f.x) and one of (r.y, f.y) is non-zero, so the clamped coordinates separate:
+// offset(vx, vy) = U[vx] + Vv[vy] with 2V precomputed terms.
 template <int V>
 __device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, const uint32_t* lut, uint32_t me, uint32_t ck,
                                          uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t& vm) {
@@ -106,6 +117,16 @@ __device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, cons
   const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
   const int rx = -fy, ry = fx;
   const int x0 = x + fx * (V - 1) - rx * (V / 2), y0 = y + fy * (V - 1) - ry * (V / 2);   // view cell (0,0)
+  const int PW = p.W + 2;
+  const int cx0 = min(max(x0, -1), p.W), cy0 = min(max(y0, -1), p.H);
+  int U[V], Vv[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int ux = min(max(x0 + i * rx, -1), p.W) - cx0, uy = min(max(y0 + i * ry, -1), p.H) - cy0;
+    const int wx = min(max(x0 - i * fx, -1), p.W) + 1, wy = min(max(y0 - i * fy, -1), p.H) + 1;
+    U[i] = (uy * PW + ux) * kCellB;
+    Vv[i] = (wy * PW + wx) * kCellB;
+  }
   uint32_t code[V * V];
   uint32_t opq[V];
 #pragma unroll
@@ -114,43 +135,99 @@ __device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, cons
   for (int vx = 0; vx < V; ++vx)
 #pragma unroll
     for (int vy = 0; vy < V; ++vy) {
-      const int wx = x0 + vx * rx - vy * fx, wy = y0 + vx * ry - vy * fy;
-      const bool inb = (unsigned)wx < (unsigned)p.W && (unsigned)wy < (unsigned)p.H;
-      const uint32_t k = g_get(g, inb ? wy * p.W + wx : 0);
-      const uint32_t w = lut[inb ? k : K_WALL];
+      const uint32_t w = lut[g_get(g, U[vx] + Vv[vy])];
       code[vx * V + vy] = w & 0xFFFFFFu;
       opq[vy] |= ((w >> 24) & 1u) << vx;
     }
   pack_view<V>(code, opq, p.see_through != 0, lut[ck] & 0xFFFFFFu, s, vm);
 }
 
+// Inputs of one chunk, requested one chunk ahead with inline-asm loads and retired with a counted
+// s_waitcnt (see load_chunk / wait_chunk in mgrid.hip for why).
+template <int A>
+struct DynIn {
+  uint32_t st[4];           // env_state words (A + 1 used)
+  uint32_t carry, act;
+  uint32_t pre[kPreMax];    // this lane's share of the chunk's grid rows (dword lane + 64k), GW <= kPreMax only
+};
+
+template <int A>
+__device__ __forceinline__ void dyn_load(const Params& p, int64_t env0, int lane, DynIn<A>& in) {
+  const int64_t n = env0 + lane;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) in.st[a] = 0u;
+#pragma unroll
+  for (int a = 0; a <= A; ++a) in.st[a] = asm_load_u32(p.env_state + n * (A + 1) + a);
+  in.carry = asm_load_u32(p.carry + n);
+  in.act = 0x06060606u;
+  if (p.op == OP_STEP && !p.random_actions) in.act = asm_load_u32(p.actions + n);
+  const uint32_t* ghbm = p.grid + (env0 >> 6) * (int64_t)p.GW * kWave + lane;
+#pragma unroll
+  for (int k = 0; k < kPreMax; ++k) {
+    in.pre[k] = 0u;
+    if (k < p.GW && p.GW <= kPreMax) in.pre[k] = asm_load_u32(ghbm + k * kWave);
+  }
+}
+
+template <int A, int K>
+__device__ __forceinline__ void dyn_wait(DynIn<A>& in) {
+  static_assert(A <= 3 && kPreMax == 16, "operand list below");
+  asm volatile("s_waitcnt vmcnt(%22)"
+               : "+v"(in.st[0]), "+v"(in.st[1]), "+v"(in.st[2]), "+v"(in.st[3]),
+                 "+v"(in.carry), "+v"(in.act),
+                 "+v"(in.pre[0]), "+v"(in.pre[1]), "+v"(in.pre[2]), "+v"(in.pre[3]), "+v"(in.pre[4]), "+v"(in.pre[5]),
+                 "+v"(in.pre[6]), "+v"(in.pre[7]), "+v"(in.pre[8]), "+v"(in.pre[9]), "+v"(in.pre[10]), "+v"(in.pre[11]),
+                 "+v"(in.pre[12]), "+v"(in.pre[13]), "+v"(in.pre[14]), "+v"(in.pre[15])
+               : "n"(K)
+               : "memory");
+}
+
 // One chunk (64 envs) of one step()/reset() on mutable grids.
 template <int A, int V>
 __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, const uint32_t* lut, const uint32_t* base,
-                                          uint32_t* stage, uint32_t* gw, int lane, int64_t env0, uint32_t& err_acc) {
+                                          const uint16_t* pidx, uint32_t* stage, uint32_t* gw, int lane, int64_t env0,
+                                          const DynIn<A>& in, uint32_t& err_acc) {
   constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
   const int64_t n = env0 + lane;
   const bool active = n < p.n_envs;
   const uint32_t gid = (uint32_t)(p.gid_base + (uint64_t)n);
   const uint32_t all = (1u << A) - 1u;
+  const int cells = p.W * p.H;
 
-  // ---- this wave's 64 grids: HBM -> LDS (lane l moves dword (j, l): its own env's) ------------
+  // ---- this wave's 64 grids: HBM rows -> padded LDS grid.  Dword d = lane + 64k of the chunk holds
+  //      lanes 4*(d%16)..+3 of cell d/16; it goes to LDS dword pidx[cell]*17 + d%16. ---------------
   uint32_t* const ghbm = p.grid + (env0 >> 6) * (int64_t)p.GW * kWave;
-  for (int j = 0; j < p.GW; ++j) gw[j * kWave + lane] = ghbm[j * kWave + lane];
-  uint8_t* const g = reinterpret_cast<uint8_t*>(gw + lane);
+  const int l4 = lane & 15, c4 = lane >> 4;
+  if (p.GW <= kPreMax) {
+#pragma unroll
+    for (int k = 0; k < kPreMax; ++k) {
+      const int ci = c4 + 4 * k;
+      if (k < p.GW && ci < cells) gw[(int)pidx[ci] * kCellW + l4] = in.pre[k];
+    }
+  } else {
+    for (int k = 0; k < p.GW; ++k) {
+      const int ci = c4 + 4 * k;
+      if (ci < cells) gw[(int)pidx[ci] * kCellW + l4] = ghbm[k * kWave + lane];
+    }
+  }
+  // the rows above were written by other lanes than the ones that read them below
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  uint8_t* const g = reinterpret_cast<uint8_t*>(gw) + lane;
 
   uint64_t pd = 0;
   uint32_t shw[A];
   uint32_t actw = 0, err = 0;
 #pragma unroll
   for (int a = 0; a < A; ++a) {
-    const uint32_t w = p.env_state[n * (A + 1) + a];
+    const uint32_t w = in.st[a];
     const uint32_t cx = min(w & 63u, (uint32_t)(p.W - 1)), cy = min((w >> 6) & 63u, (uint32_t)(p.H - 1));
     pd |= (uint64_t)(cx | (cy << 6) | (w & 0x3000u)) << (14 * a);
     shw[a] = w & ~AW_POSDIR;
   }
-  uint32_t st = p.env_state[n * (A + 1) + A];
-  uint32_t carry = p.carry[n];
+  uint32_t st = in.st[A];
+  uint32_t carry = in.carry;
   // agents (re)spawn at x < spawn_w: the DoorKey split (doorkey.py:77-78), the whole grid otherwise
   int spawn_w = p.kind == MG_KIND_STATIC ? p.W : (int)min((st >> 24) & 63u, (uint32_t)p.W);
   uint32_t done_flag = 0;
@@ -159,9 +236,8 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   if (is_step) {
     if (p.random_actions) actw = draw_actions<A>(p, n, gid, active);
     else {
-      const uint32_t aw = p.actions[n];
 #pragma unroll
-      for (int a = 0; a < A; ++a) actw |= min((aw >> (8 * a)) & 255u, 7u) << (3 * a);
+      for (int a = 0; a < A; ++a) actw |= min((in.act >> (8 * a)) & 255u, 7u) << (3 * a);
     }
     uint32_t step = (st & 0xFFFFu) + 1u;                                        // multigrid.py:968
     uint32_t dbits = (st >> 16) & all;
@@ -180,11 +256,11 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       bool blocked = false;                                                     // another agent in front
 #pragma unroll
       for (int b = 0; b < A; ++b) blocked = blocked || (b != a && (pd_get(pd, b) & AW_POS) == fpos);
-      // agents live inside the border wall, so the front cell is on the grid; a map without a
-      // border makes the reference fault (Grid.get asserts) — here the outside reads as wall
-      const bool inb = (unsigned)fx < (unsigned)p.W && (unsigned)fy < (unsigned)p.H;
-      const int ci = inb ? fy * p.W + fx : 0;
-      const uint32_t kf = inb ? g_get(g, ci) : K_WALL;
+      // the front cell of an agent on the grid is on the grid or on the ring of walls; nothing below
+      // ever writes to a wall cell, so the ring stays intact.  (A map without a border wall makes the
+      // reference fault in Grid.get; here the outside simply reads as wall.)
+      const int ci = g_off(p, fx, fy);
+      const uint32_t kf = g_get(g, ci);
       const uint32_t fl = lut[kf];
       const uint32_t ck = (carry >> (8 * a)) & 255u;
       const int nd = (act == 0u) ? ((d + 3) & 3) : (act == 1u) ? ((d + 1) & 3) : d;   // :867-876
@@ -199,7 +275,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
               // agent's old cell still counts as occupied (agent_pos is cleared only afterwards, :655)
               const bool inj = p.objdrop != nullptr;
               const uint32_t w = place_dyn<A>(p, g, pd, all, a, P_OBJDROP, p.W, inj, inj ? p.objdrop[n * A + a] : 0u, false, gid);
-              g_set(g, aw_y(w) * p.W + aw_x(w), ck);
+              g_set(g, g_off(p, aw_x(w), aw_y(w)), ck);
               carry &= ~(255u << (8 * a));
               err |= w >> 16;
             }
@@ -264,7 +340,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   // ---- reset() (multigrid.py:466-501) / auto-reset: _gen_grid on this env's own grid ------------
   const bool do_reset = (!is_step) ? (p.mask ? (p.mask[active ? n : 0] != 0) : true) : (done_flag && p.auto_reset);
   if (do_reset) {
-    for (int j = 0; j < p.GW; ++j) gw[j * kWave + lane] = base[j];
+    for (int ci = 0; ci < cells; ++ci) g_set(g, (int)pidx[ci] * kCellB, (base[ci >> 2] >> (8 * (ci & 3))) & 255u);
     carry = 0u;                                                                 // multigrid.py:490
     int door = 1;
     const bool inj_gen = p.reset_gen != nullptr;
@@ -279,7 +355,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
         door = 1 + (int)__umulhi(r.y, (uint32_t)(p.W - 3));                     // _rand_int(1, width-2)
       }
       if (split < 1 || split > p.W - 2 || door < 1 || door > p.H - 2) { err |= MG_ERR_BAD_RESPAWN; split = start; door = 1; }
-      for (int j = 0; j < p.H; ++j) g_set(g, j * p.W + split, K_WALL);          // vert_wall(split_idx, 0)
+      for (int j = 0; j < p.H; ++j) g_set(g, g_off(p, split, j), K_WALL);       // vert_wall(split_idx, 0)
       spawn_w = split;
     }
 #pragma unroll 1
@@ -291,9 +367,9 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       err |= w >> 16;
     }
     if (p.kind == MG_KIND_DOORKEY) {                                            // doorkey.py:58-65
-      g_set(g, door * p.W + spawn_w, K_DOOR_YELLOW_LOCKED);
+      g_set(g, g_off(p, spawn_w, door), K_DOOR_YELLOW_LOCKED);
       const uint32_t w = place_dyn<A>(p, g, pd, all, 0, P_KEY, spawn_w, inj_gen, genw >> 16, false, gid);
-      g_set(g, aw_y(w) * p.W + aw_x(w), K_KEY_YELLOW);
+      g_set(g, g_off(p, aw_x(w), aw_y(w)), K_KEY_YELLOW);
       err |= w >> 16;
     }
 #pragma unroll
@@ -313,10 +389,18 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     else reinterpret_cast<uint64_t*>(p.dir_done)[n] = dd;
     err_acc |= err;
   }
-  // ---- grids: LDS -> HBM (padding lanes write their own, unused, slots) ------------------------
-  for (int j = 0; j < p.GW; ++j) ghbm[j * kWave + lane] = gw[j * kWave + lane];
+  // ---- grids: LDS -> HBM rows (the reverse of the copy above; padding lanes' bytes are unused) ---
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+  for (int k = 0; k < p.GW; ++k) {
+    const int ci = c4 + 4 * k;
+    if (ci < cells) ghbm[k * kWave + lane] = gw[(int)pidx[ci] * kCellW + l4];
+  }
 
   // ---- gen_obs (multigrid.py:1037-1067) --------------------------------------------------------
+#if MG_ABL != 2
 #pragma unroll
   for (int a = 0; a < A; ++a) {
     uint32_t s[NW + 1];
@@ -324,40 +408,74 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     dyn_view<V>(p, g, lut, pd_get(pd, a), (carry >> (8 * a)) & 255u, s, vm);
     emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB);
   }
+#endif
 }
 
 template <int A, int V>
 __global__ __launch_bounds__(256) void mg_dyn_kernel(const Params p) {
   constexpr int ROWB = ViewGeom<V>::ROWB;
   extern __shared__ __align__(16) uint8_t smem[];
-  // LDS carve: [stage: nw x 64*ROWB B][grids: nw x GW*256 B][dist LUT: W*H f64][kind LUT: 256 u32][base: GW u32]
+  // LDS carve: [stage: nw x 64*ROWB B][grids: nw x (W+2)(H+2)*68 B][dist LUT: W*H f64][kind LUT: 256 u32]
+  //            [base: GW u32][pidx: W*H u16]
   const int nw = blockDim.x >> 6;
+  const int pcells = (p.W + 2) * (p.H + 2), cells = p.W * p.H;
   uint32_t* stage_all = reinterpret_cast<uint32_t*>(smem);
   uint32_t* grids = reinterpret_cast<uint32_t*>(smem + (size_t)nw * kWave * ROWB);
-  double* dist = reinterpret_cast<double*>(grids + (size_t)nw * p.GW * kWave);
-  uint32_t* lut = reinterpret_cast<uint32_t*>(dist + p.W * p.H);
+  double* dist = reinterpret_cast<double*>(grids + (size_t)nw * pcells * kCellW + ((nw * pcells * kCellW) & 1));
+  uint32_t* lut = reinterpret_cast<uint32_t*>(dist + cells);
   uint32_t* base = lut + 256;
+  uint16_t* pidx = reinterpret_cast<uint16_t*>(base + p.GW);
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
+
+  // persistent: each wave strides over the 64-env chunks; the first chunk's inputs are requested
+  // before the LDS tables are filled
+  const int64_t cstride = (int64_t)gridDim.x * nw;
+  int64_t c = (int64_t)blockIdx.x * nw + wv;
+  DynIn<A> cur, nxt;
+  if (c < p.n_chunks) dyn_load<A>(p, c * kWave, lane, cur);
+
   for (int i = tid; i < 256; i += blockDim.x) lut[i] = kind_word((uint32_t)i);
   for (int i = tid; i < p.GW; i += blockDim.x) base[i] = p.base_grid[i];
-  for (int i = tid; i < p.W * p.H; i += blockDim.x) dist[i] = p.dist_lut[i];
+  for (int i = tid; i < cells; i += blockDim.x) {
+    dist[i] = p.dist_lut[i];
+    pidx[i] = (uint16_t)((i / p.W + 1) * (p.W + 2) + (i % p.W) + 1);
+  }
+  // every wave's padded grid starts as all grey wall: the ring is never written again
+  for (int i = tid; i < nw * pcells * kCellW; i += blockDim.x) grids[i] = K_WALL * 0x01010101u;
   __syncthreads();
+
   uint32_t* stage = stage_all + wv * (kWave * ROWB / 4);
-  uint32_t* gw = grids + (size_t)wv * p.GW * kWave;
+  uint32_t* gw = grids + (size_t)wv * pcells * kCellW;
   uint32_t err = 0;
-  const int64_t cstride = (int64_t)gridDim.x * nw;
-  for (int64_t c = (int64_t)blockIdx.x * nw + wv; c < p.n_chunks; c += cstride)
-    dyn_chunk<A, V>(p, dist, lut, base, stage, gw, lane, c * kWave, err);
+  // vector-memory operations a chunk issues after the next chunk's prefetch, all of them for at
+  // least one lane: grid rows, obs stores, env_state, carry, dir_done (rewards in a step on top)
+#if MG_ABL == 0
+  constexpr int kObs = A * ((4 * ROWB + kWave - 1) / kWave);
+#else
+  constexpr int kObs = 0;
+#endif
+  constexpr int kLo = (kObs + A + 3) < 63 ? (kObs + A + 3) : 63;               // + GW unknown at compile time
+  constexpr int kHi = (kObs + A + 3 + 16) < 63 ? (kObs + A + 3 + 16) : 63;     // GW == 16 (8x8)
+  if (c < p.n_chunks) dyn_wait<A, 0>(cur);
+  for (; c < p.n_chunks; c += cstride) {
+    const int64_t cn = c + cstride;
+    const bool more = cn < p.n_chunks;          // wave-uniform
+    if (more) dyn_load<A>(p, cn * kWave, lane, nxt);
+    dyn_chunk<A, V>(p, dist, lut, base, pidx, stage, gw, lane, c * kWave, cur, err);
+    if (more) {
+      if (p.GW == 16) dyn_wait<A, kHi>(nxt); else dyn_wait<A, kLo>(nxt);
+      cur = nxt;
+    }
+  }
   if (err) atomicOr(p.err, err);
 }
 
 // mg_export_grid: de-block the per-env grids into plain [n][W*H] byte arrays
-__global__ void export_grid_kernel(const uint32_t* grid, int GW, int cells, int64_t n_envs, uint8_t* out) {
+__global__ void export_grid_kernel(const uint8_t* grid, int GW, int cells, int64_t n_envs, uint8_t* out) {
   const int64_t total = n_envs * cells;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = i / cells;
     const int ci = (int)(i - n * cells);
-    const uint32_t w = grid[((n >> 6) * GW + (ci >> 2)) * kWave + (n & 63)];
-    out[i] = (uint8_t)(w >> (8 * (ci & 3)));
+    out[i] = grid[((n >> 6) * GW * 4 + ci) * kWave + (n & 63)];
   }
 }

@@ -860,8 +860,8 @@ void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid
 void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* lds_out) {
   const mg_config& c = h->cfg;
   const size_t rowb = (size_t)c.view_size * c.view_size * 3;
-  const size_t fixed = ((size_t)c.width * c.height * 8 + 256 * 4 + (size_t)h->GW * 4 + 15) / 16 * 16;
-  const size_t per_wave = (size_t)kWave * rowb + (size_t)h->GW * kWave * 4;
+  const size_t fixed = ((size_t)c.width * c.height * 10 + 256 * 4 + (size_t)h->GW * 4 + 8 + 15) / 16 * 16;
+  const size_t per_wave = (size_t)kWave * rowb + (size_t)(c.width + 2) * (c.height + 2) * kCellB;
   int nw = 4;
   while (nw > 1 && (fixed + nw * per_wave > (size_t)kLdsLimit || h->n_chunks < (int64_t)h->n_cu * nw)) nw >>= 1;
   const size_t lds = fixed + nw * per_wave;
@@ -1229,7 +1229,8 @@ int mg_export_grid(mg_handle* h, uint8_t* out) {
   const int cells = h->cfg.width * h->cfg.height;
   const int64_t total = h->cfg.n_envs * cells;
   const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65536);
-  hipLaunchKernelGGL(export_grid_kernel, dim3(blocks), dim3(256), 0, h->stream, h->grid, h->GW, cells, h->cfg.n_envs, out);
+  hipLaunchKernelGGL(export_grid_kernel, dim3(blocks), dim3(256), 0, h->stream, reinterpret_cast<const uint8_t*>(h->grid), h->GW,
+                     cells, h->cfg.n_envs, out);
   HIP_TRY(hipGetLastError());
   return MG_OK;
 }

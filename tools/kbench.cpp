@@ -1,5 +1,7 @@
 // kbench — torch-free micro-benchmark of the step kernel for A/B work.
 // usage: kbench <map.bin> <n_envs> <steps> <rounds> lib1.so [lib2.so ...]
+// env MG_WORKLOAD=doorkey<size>x<agents> (e.g. doorkey8x3) times the mutable-grid kernel on DoorKey instead of
+// the Cluttered map (the map argument is still read but unused).
 // Each library is dlopen'ed separately (its own copy of the kernels); rounds are interleaved
 // across libraries in one process (cdna_hip_programming.md §5.4 rule 24).
 #include <dlfcn.h>
@@ -41,6 +43,12 @@ int main(int argc, char** argv) {
   if (!f || fread(cells.data(), 1, cells.size(), f) != cells.size()) { fprintf(stderr, "bad map\n"); return 2; }
   fclose(f);
   const int R = 16;
+  int dk_size = 0, dk_agents = 0;
+  if (const char* w = getenv("MG_WORKLOAD")) sscanf(w, "doorkey%dx%d", &dk_size, &dk_agents);
+  const int A = dk_size ? dk_agents : 3, V = dk_size ? 7 : 5;
+  // bytes one env-step has to move: obs + dir_done + rewards + actions + env_state r/w (+ carry and grid r/w)
+  const double env_bytes = A * V * V * 3 + (A < 4 ? 4 : 8) + 8.0 * A + 4 + 8.0 * (A + 1) +
+                           (dk_size ? 8 + 2.0 * ((dk_size * dk_size + 3) / 4 * 4) : 0);
   std::vector<Api> apis;
   for (int i = 5; i < argc; ++i) {
     Api a{};
@@ -53,8 +61,12 @@ int main(int argc, char** argv) {
     c.width = c.height = 15; c.n_agents = 3; c.view_size = 5; c.max_steps = 100; c.shaping_kind = MG_SHAPING_V8;
     c.auto_reset = 1; c.n_envs = n; c.seed = 0xC0FFEE;
     c.kernel_path = getenv("MG_PATH") ? atoi(getenv("MG_PATH")) : 0;
+    if (dk_size) {
+      c.width = c.height = dk_size; c.n_agents = dk_agents; c.view_size = 7; c.max_steps = 10 * dk_size * dk_size;
+      c.env_kind = MG_KIND_DOORKEY;
+    }
     if (a.create(&c, 0, &a.h) != MG_OK) { fprintf(stderr, "create: %s\n", a.last_error()); return 1; }
-    if (a.set_map(a.h, cells.data()) != MG_OK) { fprintf(stderr, "map: %s\n", a.last_error()); return 1; }
+    if (!dk_size && a.set_map(a.h, cells.data()) != MG_OK) { fprintf(stderr, "map: %s\n", a.last_error()); return 1; }
     mg_buffers b;
     a.get_buffers(a.h, &b);
     const size_t sz = (size_t)4 * b.env_stride;
@@ -66,7 +78,8 @@ int main(int argc, char** argv) {
     void* st; a.get_stream(a.h, &st); a.stream = (hipStream_t)st;
     a.reset(a.h, nullptr);
     for (int k = 0; k < 50; ++k) a.step(a.h, a.ring + (size_t)(k % R) * sz);
-    a.sync(a.h);
+    // stop at the first library whose warm-up does not complete cleanly: nothing later is launched on a faulted device
+    if (a.sync(a.h) != MG_OK || hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "%s: warm-up failed: %s\n", argv[i], a.last_error()); return 3; }
     apis.push_back(a);
   }
   hipEvent_t e0, e1;
@@ -78,16 +91,19 @@ int main(int argc, char** argv) {
       hipEventRecord(e0, a.stream);
       for (int k = 0; k < steps; ++k) a.step(a.h, a.ring + (size_t)(k % R) * sz);
       hipEventRecord(e1, a.stream);
-      hipEventSynchronize(e1);
-      float ms; hipEventElapsedTime(&ms, e0, e1);
+      float ms = 0.f;
+      if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+        fprintf(stderr, "timing failed (device error)\n"); return 3;
+      }
       a.us.push_back(ms * 1e3f / steps);
     }
   for (size_t i = 0; i < apis.size(); ++i) {
     auto v = apis[i].us; std::sort(v.begin(), v.end());
     const float med = v[v.size() / 2], mn = v.front();
     uint32_t err = 0; apis[i].check(apis[i].h, &err);
-    printf("%-40s n=%lld  median %.2f us  min %.2f us  alg %.0f GB/s (%.1f%% of 8 TB/s)  %.3e agent-steps/s  err=%u\n",
-           argv[5 + i], (long long)n, med, mn, 308.0 * n / med / 1e3, 308.0 * n / med / 1e3 / 80.0, 3.0 * n / (med * 1e-6), err);
+    printf("%-40s n=%lld  median %.2f us  min %.2f us  alg %.0f GB/s (%.1f%% of 8 TB/s, %.0f B/env-step)  %.3e agent-steps/s  err=%u\n",
+           argv[5 + i], (long long)n, med, mn, env_bytes * n / med / 1e3, env_bytes * n / med / 1e3 / 80.0, env_bytes,
+           (double)A * n / (med * 1e-6), err);
   }
   return 0;
 }
