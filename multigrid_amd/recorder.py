@@ -1,0 +1,350 @@
+"""Trajectory recorder, fixture format and replay tool.
+
+No reference counterpart (the closest is the per-step dict collection of
+generate_trajectory_video.py:180-241).  Purpose: make bit-exact parity reproducible on any box.
+
+* `Recorder` drives ANY env object with the reference's duck type — `reset()`, `step(list)`,
+  `.agent_pos/.agent_dir/.carrying/.grid.get(i, j)/.n_agents/.width/.height/.max_steps/
+  .agent_view_size` (envs/gym_multigrid/multigrid.py:322-1083) — and captures everything the HIP
+  path needs to replay the run bit for bit, without touching the env's RNGs:
+    - the per-step agent order, by spying on `numpy.random.shuffle` (multigrid.py:973-974);
+    - every accepted placement, by wrapping the env instance's `place_one_agent` / `place_obj`
+      (multigrid.py:560-661): spawns at reset, respawns and re-placed carried objects in a step,
+      the DoorKey key; the DoorKey split / door are read back from the generated grid.
+  On a box that has gym==0.23.1 and gym-minigrid==1.0.3 the env can be the real reference env
+  (`python -m multigrid_amd.recorder record --reference /path/to/cxh42-multigrid ...`); fixtures
+  recorded that way replace the restatement-generated ones under tests/golden/ and clear the
+  "parity unpinned" flag.  That leg cannot run in the build container (packages absent).
+* `save` / `load`: one `.npz` per fixture, schema below.
+* `replay_on_device`: runs the fixture through libmgrid.so in replay mode (one device env per
+  recorded episode) and compares every recorded output; used by tests and by the CLI.
+
+Fixture schema (E episodes, T = longest episode, A agents, V view size):
+  meta          json: schema, kind ('static' | 'doorkey'), width, height, n_agents, view_size,
+                max_steps, see_through_walls, competitive, shaping ('none' | 'v8'), source
+  cells         uint8[H, W, 3]            layout (kind 'static'), encode() triples
+  length        int32[E]                  steps recorded for the episode (it ended with done, or at T)
+  spawn         int8[E, A, 4]             (x, y, dir, 0) accepted at reset
+  gen           int8[E, 4]                DoorKey (split_idx, door_idx, key_x, key_y)
+  actions       uint8[E, T, A]
+  order         uint8[E, T, A]            order[e, t, k] = agent acting k-th
+  respawn       int8[E, T, A, 4]          (x, y, dir, 0) if agent a finished in that step, x = -1 otherwise
+  objdrop       int8[E, T, A, 4]          (x, y, 0, 0) where the object it carried was re-placed, x = -1 otherwise
+  obs_image     uint8[E, T+1, A, V, V, 3] index 0 = the reset observation
+  obs_dir       uint8[E, T+1, A]
+  env_reward    float64[E, T, A]
+  shaped_reward float64[E, T, A]          only when a shaper was attached
+  done          uint8[E, T]
+  agent_pos     uint8[E, T+1, A, 2], agent_dir uint8[E, T+1, A], carry uint8[E, T+1, A] (kind ids)
+Steps past an episode's length are zero padding.
+"""
+import json
+from unittest import mock
+
+import numpy as np
+
+SCHEMA = 1
+
+
+def _kind_id(enc):
+  t, c, s = (int(v) for v in enc)
+  if t in (0, 1, 10):
+    return 0
+  return 128 + c * 4 + s if t == 4 else t * 8 + c
+
+
+class Recorder:
+  """Wraps one env instance; `episode(policy, max_len)` returns the arrays of one episode."""
+
+  def __init__(self, env, shaper=None, kind='static'):
+    self.env = getattr(env, 'unwrapped', env)
+    self.shaper = shaper          # callable(env, rewards, actions) -> shaped rewards, with .clear()
+    self.kind = kind
+    self.A = int(self.env.n_agents)
+    self._agents, self._objects, self._orders = [], [], []
+    e = self.env
+    orig_agent, orig_obj = e.place_one_agent, e.place_obj
+
+    def place_one_agent(agent_id, *a, **k):
+      pos = orig_agent(agent_id, *a, **k)
+      self._agents.append((int(agent_id), int(pos[0]), int(pos[1]), int(e.agent_dir[agent_id])))
+      return pos
+
+    def place_obj(obj, *a, **k):
+      pos = orig_obj(obj, *a, **k)
+      if obj is not None:
+        self._objects.append((obj, int(pos[0]), int(pos[1])))
+      return pos
+
+    e.place_one_agent, e.place_obj = place_one_agent, place_obj
+
+  def _spy_shuffle(self):
+    real = np.random.shuffle
+
+    def shuffle(x):
+      real(x)
+      self._orders.append(np.array(x, dtype=np.uint8))
+
+    return mock.patch('numpy.random.shuffle', shuffle)
+
+  def _state(self):
+    e = self.env
+    pos = np.array([[int(p[0]), int(p[1])] for p in e.agent_pos], np.uint8)
+    d = np.array([int(v) for v in e.agent_dir], np.uint8)
+    carry = np.array([_kind_id(c.encode()) if c else 0 for c in e.carrying], np.uint8)
+    return pos, d, carry
+
+  def _gen(self):
+    g = np.zeros(4, np.int8)
+    if self.kind == 'doorkey':
+      e = self.env
+      split = int(e.split_idx)
+      doors = [j for j in range(e.height) if e.grid.get(split, j) is not None and e.grid.get(split, j).encode()[0] == 4]
+      keys = [(x, y) for (o, x, y) in self._objects if o.encode()[0] == 5]
+      g[:] = (split, doors[0], keys[-1][0], keys[-1][1])
+    return g
+
+  def episode(self, policy, max_len):
+    """policy(env, obs, t) -> list of A ints.  Records until done or max_len steps."""
+    e, A = self.env, self.A
+    self._agents, self._objects = [], []
+    obs = e.reset()
+    if self.shaper is not None:
+      self.shaper.clear()
+    spawn = np.zeros((A, 4), np.int8)
+    for a, x, y, d in self._agents[-A:]:
+      spawn[a] = (x, y, d, 0)
+    out = dict(spawn=spawn, gen=self._gen(), actions=[], order=[], respawn=[], objdrop=[], env_reward=[], shaped_reward=[],
+               done=[], obs_image=[np.stack(obs['image'])], obs_dir=[np.array(obs['direction'], np.uint8)])
+    pos, d, carry = self._state()
+    out.update(agent_pos=[pos], agent_dir=[d], carry=[carry])
+    with self._spy_shuffle():
+      for t in range(max_len):
+        actions = [int(a) for a in policy(e, obs, t)]
+        self._agents, self._objects, self._orders = [], [], []
+        obs, rew, done, _ = e.step(list(actions))
+        assert len(self._orders) == 1, 'expected exactly one np.random.shuffle per step (multigrid.py:973-974)'
+        resp = np.full((A, 4), -1, np.int8)
+        resp[:, 2:] = 0
+        drop = resp.copy()
+        # agent_is_done places the carried object (if any) right before the agent (multigrid.py:827-832)
+        objs = list(self._objects)
+        for a, x, y, dd in self._agents:
+          resp[a] = (x, y, dd, 0)
+        if objs:
+          carried_before = out['carry'][-1]
+          finishers = [a for a in self._orders[0] if resp[a, 0] >= 0 and carried_before[a] != 0]
+          assert len(finishers) == len(objs), 'carried-object placements do not match the finishing agents'
+          for a, (_, x, y) in zip(finishers, objs):
+            drop[a] = (x, y, 0, 0)
+        out['actions'].append(np.array(actions, np.uint8))
+        out['order'].append(self._orders[0])
+        out['respawn'].append(resp)
+        out['objdrop'].append(drop)
+        out['env_reward'].append(np.array([float(r) for r in rew], np.float64))
+        if self.shaper is not None:
+          out['shaped_reward'].append(np.array([float(r) for r in self.shaper(e, rew, actions)], np.float64))
+        out['done'].append(np.uint8(bool(done)))
+        out['obs_image'].append(np.stack(obs['image']))
+        out['obs_dir'].append(np.array(obs['direction'], np.uint8))
+        pos, d, carry = self._state()
+        out['agent_pos'].append(pos); out['agent_dir'].append(d); out['carry'].append(carry)
+        if done:
+          break
+    if self.shaper is None:
+      del out['shaped_reward']
+    return {k: (np.stack(v) if isinstance(v, list) else v) for k, v in out.items()}
+
+
+def stack_episodes(episodes, meta, cells=None):
+  """Pad E recorded episodes to a common length and stack them into one fixture dict."""
+  T = max(len(ep['actions']) for ep in episodes)
+  rec = {'length': np.array([len(ep['actions']) for ep in episodes], np.int32)}
+  for k in episodes[0]:
+    arrs = []
+    for ep in episodes:
+      v = ep[k]
+      if k in ('spawn', 'gen'):
+        arrs.append(v)
+        continue
+      full = T + 1 if k in ('obs_image', 'obs_dir', 'agent_pos', 'agent_dir', 'carry') else T
+      pad = np.zeros((full,) + v.shape[1:], v.dtype)
+      pad[:v.shape[0]] = v
+      arrs.append(pad)
+    rec[k] = np.stack(arrs)
+  meta = dict(meta, schema=SCHEMA)
+  rec['meta'] = np.array(json.dumps(meta))
+  if cells is not None:
+    rec['cells'] = np.ascontiguousarray(cells, np.uint8)
+  return rec
+
+
+def save(path, rec):
+  np.savez_compressed(path, **rec)
+
+
+def load(path):
+  """Fixture dict with `meta` decoded; files written before the schema existed (the round-1 golden
+  replay fixture) get their meta from the array shapes."""
+  z = np.load(path, allow_pickle=False)
+  rec = {k: z[k] for k in z.files}
+  if 'meta' in rec:
+    rec['meta'] = json.loads(str(rec['meta']))
+  else:
+    E, T, A = rec['actions'].shape
+    H, W = rec['cells'].shape[:2]
+    rec['meta'] = dict(schema=0, kind='static', width=W, height=H, n_agents=A, view_size=int(rec['obs_image'].shape[3]),
+                       max_steps=T, see_through_walls=False, competitive=False,
+                       shaping='v8' if 'shaped_reward' in rec else 'none', source='pre-schema fixture')
+    rec['length'] = np.full(E, T, np.int32)
+  E, T, A = rec['actions'].shape
+  rec.setdefault('gen', np.zeros((E, 4), np.int8))
+  if 'objdrop' not in rec:
+    rec['objdrop'] = np.full((E, T, A, 4), -1, np.int8)
+    rec['objdrop'][..., 2:] = 0
+  return rec
+
+
+def replay_on_device(rec, device=0, check_state=True):
+  """Replay a fixture through libmgrid.so (one device env per episode, replay mode, no auto-reset) and
+  compare every recorded output bit for bit.  Returns {'episodes', 'steps', 'mismatches': {name: count}}."""
+  import torch
+  from .batched import BatchedMultiGrid
+  m = rec['meta']
+  E, T, A = rec['actions'].shape
+  shaped = 'shaped_reward' in rec
+  kw = dict(n_envs=E, n_agents=A, view_size=m['view_size'], max_steps=m['max_steps'],
+            see_through_walls=bool(m.get('see_through_walls', False)), competitive=bool(m.get('competitive', False)),
+            shaping='v8' if shaped else None, auto_reset=False, device=device, emit_env_reward=True)
+  if m['kind'] == 'doorkey':
+    env = BatchedMultiGrid(None, kind='doorkey', size=m['width'], **kw)
+  else:
+    env = BatchedMultiGrid(rec['cells'], **kw)
+  dev = env.device
+  am = lambda x: torch.from_numpy(np.ascontiguousarray(np.moveaxis(x, 0, 1))).to(dev)   # [E, A, ...] -> [A, E, ...]
+  bad = {}
+
+  def cmp(name, got, want, live):
+    n = int((np.asarray(got)[live] != np.asarray(want)[live]).sum())
+    if n:
+      bad[name] = bad.get(name, 0) + n
+
+  try:
+    if env.mutable_grid:
+      env.reset(spawn=am(rec['spawn']), gen=torch.from_numpy(rec['gen']).to(dev) if m['kind'] == 'doorkey' else None)
+    else:
+      env.reset(spawn=am(rec['spawn']))
+    live = rec['length'] >= 0
+    cmp('obs_image[0]', env.obs_image.cpu().numpy().transpose(1, 0, 2, 3, 4), rec['obs_image'][:, 0], live)
+    cmp('obs_dir[0]', env.obs_dir.cpu().numpy().T, rec['obs_dir'][:, 0], live)
+    steps = 0
+    for t in range(T):
+      live = rec['length'] > t
+      if not live.any():
+        break
+      act = rec['actions'][:, t].copy()
+      act[~live] = 6                                     # finished episodes idle
+      order = rec['order'][:, t].copy()
+      order[~live] = np.arange(A, dtype=np.uint8)
+      extra = dict(objdrop=am(rec['objdrop'][:, t])) if env.mutable_grid else {}
+      env.step_replay(am(act), am(order), am(rec['respawn'][:, t]), **extra)
+      steps += int(live.sum())
+      cmp('obs_image', env.obs_image.cpu().numpy().transpose(1, 0, 2, 3, 4), rec['obs_image'][:, t + 1], live)
+      cmp('obs_dir', env.obs_dir.cpu().numpy().T, rec['obs_dir'][:, t + 1], live)
+      cmp('env_reward', env.env_reward.cpu().numpy().T.view(np.int64), rec['env_reward'][:, t].view(np.int64), live)
+      if shaped:
+        cmp('shaped_reward', env.reward.cpu().numpy().T.view(np.int64), rec['shaped_reward'][:, t].view(np.int64), live)
+      cmp('done', env.done.cpu().numpy(), rec['done'][:, t], live)
+      if check_state:
+        cmp('agent_pos', env.agent_pos.cpu().numpy().transpose(1, 0, 2), rec['agent_pos'][:, t + 1], live)
+        cmp('agent_dir', env.agent_dir.cpu().numpy().T, rec['agent_dir'][:, t + 1], live)
+        if env.mutable_grid and 'carry' in rec:
+          c = env.carry.cpu().numpy().view(np.uint32)
+          got = np.stack([(c >> (8 * a)) & 255 for a in range(A)], axis=1)
+          cmp('carry', got, rec['carry'][:, t + 1], live)
+    err = env.check_errors()
+    if err:
+      bad['device_error_word'] = err
+  finally:
+    env.close()
+  return {'episodes': int(E), 'steps': steps, 'mismatches': bad}
+
+
+# ---- recording from the real reference (needs gym==0.23.1 + gym-minigrid==1.0.3; not runnable in the build container) ----
+class _V8Shaper:
+  """Calls the reference's own SimpleController.shape_rewards (v8_robust_ppo.py:171-220) on a bare
+  namespace, so that no networks are built."""
+
+  def __init__(self, v8_module, env):
+    import types
+    self.ns = types.SimpleNamespace(env=env, n_agents=env.n_agents)
+    self.ctl = v8_module.SimpleController
+    self.ns.get_goal_position = lambda: self.ctl.get_goal_position(self.ns)
+    self.clear()
+
+  def clear(self):
+    n = self.ns.n_agents
+    self.ns.prev_distances, self.ns.prev_positions, self.ns.stationary_count = [None] * n, [None] * n, [0] * n
+
+  def __call__(self, env, rewards, actions):
+    return self.ctl.shape_rewards(self.ns, [env.agent_pos[i] for i in range(env.n_agents)], rewards, actions)
+
+
+def record_reference(reference_path, env_id, episodes, seed=0, shaping='v8', max_len=None):
+  import importlib
+  import sys
+  sys.path.insert(0, reference_path)
+  try:
+    import gym
+    importlib.import_module('envs.gym_multigrid.multigrid_envs')
+  except ImportError as e:
+    raise SystemExit('recording from the reference needs gym==0.23.1 and gym-minigrid==1.0.3 (and numpy<1.24): %s' % e)
+  env = gym.make(env_id)
+  base = env.unwrapped
+  kind = 'doorkey' if 'DoorKey' in env_id else 'static'
+  shaper = _V8Shaper(importlib.import_module('v8_robust_ppo'), base) if shaping == 'v8' else None
+  rec = Recorder(base, shaper=shaper, kind=kind)
+  rng = np.random.RandomState(seed)
+  policy = lambda e, obs, t: rng.randint(0, 7, size=e.n_agents)
+  eps = [rec.episode(policy, max_len or base.max_steps) for _ in range(episodes)]
+  cells = None
+  if kind == 'static':
+    base.reset()
+    cells = np.zeros((base.height, base.width, 3), np.uint8)
+    for y in range(base.height):
+      for x in range(base.width):
+        c = base.grid.get(x, y)
+        cells[y, x] = (1, 0, 0) if (c is None or c.type == 'agent') else c.encode()
+  meta = dict(kind=kind, width=base.width, height=base.height, n_agents=base.n_agents, view_size=base.agent_view_size,
+              max_steps=base.max_steps, see_through_walls=bool(base.see_through_walls), competitive=bool(base.competitive),
+              shaping=shaping or 'none', source='reference %s via gym.make(%r)' % (reference_path, env_id))
+  return stack_episodes(eps, meta, cells)
+
+
+def main(argv=None):
+  import argparse
+  ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
+  sub = ap.add_subparsers(dest='cmd', required=True)
+  r = sub.add_parser('record', help='record a fixture from the real reference env (needs its pip packages)')
+  r.add_argument('--reference', required=True)
+  r.add_argument('--env-id', default='MultiGrid-Cluttered-Fixed-15x15')
+  r.add_argument('--episodes', type=int, default=16)
+  r.add_argument('--seed', type=int, default=0)
+  r.add_argument('--shaping', default='v8', choices=['v8', 'none'])
+  r.add_argument('--out', required=True)
+  p = sub.add_parser('replay', help='replay a fixture on the GPU and compare bit for bit')
+  p.add_argument('fixture')
+  p.add_argument('--device', type=int, default=0)
+  a = ap.parse_args(argv)
+  if a.cmd == 'record':
+    rec = record_reference(a.reference, a.env_id, a.episodes, a.seed, None if a.shaping == 'none' else a.shaping)
+    save(a.out, rec)
+    print('recorded %d episodes -> %s' % (len(rec['length']), a.out))
+    return 0
+  rep = replay_on_device(load(a.fixture), a.device)
+  print(json.dumps(rep))
+  return 1 if rep['mismatches'] else 0
+
+
+if __name__ == '__main__':
+  raise SystemExit(main())

@@ -75,12 +75,31 @@ def lib():
     L.mgo_batch_step_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, u8p, i8p, i8p, i8p, i8p,
                                     C.c_uint64, u8p, u8p, f64p, f64p, u8p, u8p]
     L.mgo_batch_dyn_state.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_void_p, u8p]
+    L.mgo_set_scatter.restype = C.c_int
+    L.mgo_set_scatter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.mgo_obs_bytes.restype = C.c_int
+    L.mgo_obs_bytes.argtypes = [C.c_void_p]
+    L.mgo_reset_scatter.argtypes = [C.c_void_p, i8p, i8p, C.c_uint64]
+    L.mgo_last_scatter.restype = C.c_int
+    L.mgo_last_scatter.argtypes = [C.c_void_p, i8p]
+    L.mgo_aux_words.argtypes = [C.c_void_p, C.c_void_p]
+    L.mgo_batch_reset_scatter.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, i8p, i8p, C.c_int,
+                                          C.c_uint64, u8p, u8p]
+    L.mgo_batch_aux.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, i8p, C.c_int]
     _LIB = L
   return _LIB
 
 
-KIND_STATIC, KIND_DOORKEY = 0, 1
-KINDS = {'static': KIND_STATIC, 'doorkey': KIND_DOORKEY}
+KIND_STATIC, KIND_DOORKEY, KIND_CLUTTERED, KIND_MEETUP = 0, 1, 2, 3
+KINDS = {'static': KIND_STATIC, 'doorkey': KIND_DOORKEY, 'cluttered': KIND_CLUTTERED, 'meetup': KIND_MEETUP}
+MAXOBJ = 64
+
+
+def _configure(L, h, kind, n_goals, n_clutter, lava):
+  L.mgo_set_kind(h, KINDS[kind])
+  if kind in ('cluttered', 'meetup'):
+    if not L.mgo_set_scatter(h, n_goals, n_clutter, int(lava)):
+      raise ValueError('bad scatter generator parameters')
 
 
 def kind_id(type_, color=0, state=0):
@@ -128,13 +147,16 @@ class OracleEnv:
   """One oracle env with the reference's (obs, rewards, done, info) call shape."""
 
   def __init__(self, cells, W=15, H=15, A=3, V=5, max_steps=100, see_through=0, competitive=0,
-               shaping=0, auto_reset=0, seed=0, gid=0, kind='static'):
+               shaping=0, auto_reset=0, seed=0, gid=0, kind='static', n_goals=0, n_clutter=0, lava=False):
     self.L = lib()
     self.W, self.H, self.A, self.V = W, H, A, V
     self.h = self.L.mgo_create(W, H, A, V, max_steps, see_through, competitive, shaping, auto_reset, seed, gid)
     if not self.h:
       raise ValueError('bad oracle config')
-    self.L.mgo_set_kind(self.h, KINDS[kind])
+    _configure(self.L, self.h, kind, n_goals, n_clutter, lava)
+    self.n_obj = (n_goals + n_clutter) if kind in ('cluttered', 'meetup') else 0
+    self.full = kind == 'meetup'
+    self.img_shape = (W, H, 3) if self.full else (V, V, 3)
     if cells is not None:
       cells = np.ascontiguousarray(cells, dtype=np.uint8).reshape(W * H * 3)
       self.L.mgo_set_map(self.h, _p(cells, u8p))
@@ -146,19 +168,35 @@ class OracleEnv:
       self.h = None
 
   def _obs(self):
-    img = np.zeros((self.A, self.V, self.V, 3), np.uint8)
+    img = np.zeros((self.A,) + self.img_shape, np.uint8)
     d = np.zeros(self.A, np.uint8)
     self.L.mgo_get_obs(self.h, _p(img, u8p), _p(d, u8p))
     return {'image': [img[a] for a in range(self.A)], 'direction': [int(x) for x in d]}
 
-  def reset(self, spawn=None, gen=None):
+  def reset(self, spawn=None, gen=None, scatter=None):
+    """spawn [(x,y,dir)]*A; gen (split, door, key_x, key_y) for DoorKey; scatter [(x,y)]*n_obj for the
+    scatter kinds (accepted positions of the scattered objects in draw order)."""
     sp = None
     if spawn is not None:
       sp = np.zeros((self.A, 4), np.int8)
       sp[:, :3] = np.asarray(spawn, np.int8)
+    if self.n_obj or scatter is not None:
+      sc = None if scatter is None else np.ascontiguousarray(scatter, np.int8).reshape(self.n_obj, 2)
+      self.L.mgo_reset_scatter(self.h, _p(sp, i8p), _p(sc, i8p), self.t)
+      return self._obs()
     g = None if gen is None else np.asarray(gen, np.int8).reshape(4)
     self.L.mgo_reset_gen(self.h, _p(sp, i8p), _p(g, i8p), self.t)
     return self._obs()
+
+  def last_scatter(self):
+    out = np.zeros((MAXOBJ, 2), np.int8)
+    n = self.L.mgo_last_scatter(self.h, _p(out, i8p))
+    return out[:n]
+
+  def aux_words(self):
+    out = np.zeros(4, np.uint32)
+    self.L.mgo_aux_words(self.h, out.ctypes.data_as(C.c_void_p))
+    return out
 
   def step(self, actions, order=None, respawn=None, reset_spawn=None, objdrop=None, reset_gen=None):
     act = np.asarray(actions, np.int32)
@@ -174,7 +212,7 @@ class OracleEnv:
     if reset_spawn is not None:
       sp = np.zeros((self.A, 4), np.int8)
       sp[:, :3] = np.asarray(reset_spawn, np.int8)
-    img = np.zeros((self.A, self.V, self.V, 3), np.uint8)
+    img = np.zeros((self.A,) + self.img_shape, np.uint8)
     d = np.zeros(self.A, np.uint8)
     rw = np.zeros(self.A, np.float64)
     er = np.zeros(self.A, np.float64)
@@ -244,9 +282,10 @@ class OracleBatch:
   """n oracle envs over the product's buffer layouts."""
 
   def __init__(self, cells, n, W=15, H=15, A=3, V=5, max_steps=100, see_through=0, competitive=0,
-               shaping=0, auto_reset=0, seed=0, gid_base=0, kind='static'):
+               shaping=0, auto_reset=0, seed=0, gid_base=0, kind='static', n_goals=0, n_clutter=0, lava=False):
     self.L = lib()
     self.n, self.A, self.V, self.W, self.H = n, A, V, W, H
+    self.n_obj = (n_goals + n_clutter) if kind in ('cluttered', 'meetup') else 0
     self.stride = (n + 63) // 64 * 64
     if cells is not None:
       cells = np.ascontiguousarray(cells, dtype=np.uint8).reshape(W * H * 3)
@@ -255,11 +294,11 @@ class OracleBatch:
       h = self.L.mgo_create(W, H, A, V, max_steps, see_through, competitive, shaping, auto_reset, seed, gid_base + i)
       if not h:
         raise ValueError('bad oracle config')
-      self.L.mgo_set_kind(h, KINDS[kind])
+      _configure(self.L, h, kind, n_goals, n_clutter, lava)
       if cells is not None:
         self.L.mgo_set_map(h, _p(cells, u8p))
       self.envs[i] = h
-    cb = V * V * 3
+    cb = W * H * 3 if kind == 'meetup' else V * V * 3
     s = self.stride
     self.obs_image = np.zeros((A, s, cb), np.uint8)
     self.obs_dir = np.zeros((A, s), np.uint8)
@@ -274,10 +313,16 @@ class OracleBatch:
         self.L.mgo_destroy(self.envs[i])
         self.envs[i] = None
 
-  def reset(self, mask=None, spawn=None, gen=None):
-    """spawn int8[A,stride,4]; gen int8[stride,4] = (split, door, key_x, key_y) (DoorKey replay)."""
+  def reset(self, mask=None, spawn=None, gen=None, scatter=None):
+    """spawn int8[A,stride,4]; gen int8[stride,4] = (split, door, key_x, key_y) (DoorKey replay);
+    scatter int8[stride,n_obj,2] = accepted positions of the scattered objects (scatter kinds)."""
     m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
     sp = None if spawn is None else np.ascontiguousarray(spawn, np.int8)
+    if self.n_obj:
+      sc = None if scatter is None else np.ascontiguousarray(scatter, np.int8)
+      self.L.mgo_batch_reset_scatter(self.envs, self.n, self.stride, _p(m, u8p), _p(sp, i8p), _p(sc, i8p), self.n_obj,
+                                     self.t, _p(self.obs_image, u8p), _p(self.obs_dir, u8p))
+      return
     g = None if gen is None else np.ascontiguousarray(gen, np.int8)
     self.L.mgo_batch_reset_ex(self.envs, self.n, self.stride, _p(m, u8p), _p(sp, i8p), _p(g, i8p), self.t,
                               _p(self.obs_image, u8p), _p(self.obs_dir, u8p))
@@ -302,6 +347,14 @@ class OracleBatch:
     kinds = np.zeros((self.stride, self.H, self.W), np.uint8)
     self.L.mgo_batch_dyn_state(self.envs, self.n, self.stride, carry.ctypes.data_as(C.c_void_p), _p(kinds, u8p))
     return carry, kinds
+
+  def aux_state(self):
+    """(aux uint32[stride,4], scatter int8[stride,n_obj,2]): kind-specific state and the last layout's draws."""
+    aux = np.zeros((self.stride, 4), np.uint32)
+    aux[:, :3] = 0xFFFFFFFF
+    sc = np.zeros((self.stride, max(self.n_obj, 1), 2), np.int8)
+    self.L.mgo_batch_aux(self.envs, self.n, aux.ctypes.data_as(C.c_void_p), _p(sc, i8p), self.n_obj)
+    return aux, sc[:, :self.n_obj]
 
   def last_gen(self):
     """(gen int8[stride,4], objdrop int8[A,stride,4]) recorded by the last reset / step."""

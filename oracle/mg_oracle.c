@@ -86,7 +86,9 @@ static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
 void mgo_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
 
 enum { P_ORDER = 0, P_RESPAWN = 1, P_SPAWN = 2, P_ACTION = 3, P_GEN = 4, P_KEY = 5, P_OBJDROP = 6 };
-enum { KIND_STATIC = 0, KIND_DOORKEY = 1 };
+enum { KIND_STATIC = 0, KIND_DOORKEY = 1, KIND_CLUTTERED = 2, KIND_MEETUP = 3 };
+#define MAXOBJ 64              /* objects a scatter generator places (goals/doors + clutter) */
+#define MAXGOALS 3
 #define MAX_ATTEMPTS 256
 
 static uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
@@ -115,6 +117,14 @@ typedef struct mgo_env {
   const int8_t* inj_gen;       /* injected (split_idx, door_idx, key_x, key_y) or NULL */
   const int8_t* inj_obj;       /* injected (x, y, 0, 0) per agent for a carried object re-placed on death, or NULL */
   int8_t last_gen[4], last_objdrop[MAXA * 4];
+  /* scatter generators (ClutteredMultiGrid with random layouts, MeetupEnv): */
+  int n_goals;                 /* Cluttered: 1 = randomize_goal, 0 = goal at (W-2,H-2); Meetup: number of goal doors */
+  int n_clutter, lava;         /* obstacles per layout; Cluttered walls_are_lava */
+  int full_obs;                /* fully_observed (multigrid.py:1043-1045, 1064-1065): Meetup */
+  int goal_x[MAXGOALS], goal_y[MAXGOALS];   /* MeetupEnv.goal_pos (meetup.py:67-70) */
+  int past_dist[MAXA];         /* MeetupEnv.past_goal_dist (meetup.py:61, 94) */
+  const int8_t* inj_scatter;   /* injected accepted (x, y) of every scattered object, in draw order, or NULL */
+  int8_t last_scatter[2 * MAXOBJ]; int n_scatter;
 } mgo_env;
 
 mgo_env* mgo_create(int W, int H, int A, int V, int max_steps, int see_through, int competitive,
@@ -128,7 +138,15 @@ mgo_env* mgo_create(int W, int H, int A, int V, int max_steps, int see_through, 
   e->kind = KIND_STATIC; e->spawn_w = W;
   return e;
 }
-void mgo_set_kind(mgo_env* e, int kind) { e->kind = kind; }
+void mgo_set_kind(mgo_env* e, int kind) { e->kind = kind; e->full_obs = (kind == KIND_MEETUP); }
+/* generator parameters of the scatter kinds; returns 0 if they do not fit */
+int mgo_set_scatter(mgo_env* e, int n_goals, int n_clutter, int lava) {
+  if (n_goals < 0 || n_goals > MAXGOALS || n_clutter < 0 || n_goals + n_clutter > MAXOBJ) return 0;
+  if (e->kind == KIND_MEETUP && n_goals < 1) return 0;
+  e->n_goals = n_goals; e->n_clutter = n_clutter; e->lava = lava;
+  return 1;
+}
+int mgo_obs_bytes(const mgo_env* e) { return e->full_obs ? e->W * e->H * 3 : e->V * e->V * 3; }
 void mgo_destroy(mgo_env* e) { free(e); }
 
 /* cells: uint8[W*H*3], [(y*W+x)*3+c]; type 1 (empty) and 0 mean None */
@@ -394,10 +412,59 @@ static void gen_doorkey(mgo_env* e) {
   e->last_gen[0] = (int8_t)split; e->last_gen[1] = (int8_t)door;
 }
 
+/* place_obj(obj, max_tries=100) anywhere on the grid for scattered object number idx (cluttered.py:28-36,
+ * meetup.py:67-72).  The reference raises after 100 failed tries; here, as everywhere, the loop is
+ * bounded at MAX_ATTEMPTS and then falls back to the first free cell (unreachable in practice:
+ * more than half of every such grid is free). */
+static void place_scatter(mgo_env* e, obj_t obj, int idx, int* ox, int* oy) {
+  int8_t rec[4], inj[4] = {0, 0, 0, 0};
+  if (e->inj_scatter) { inj[0] = e->inj_scatter[2 * idx]; inj[1] = e->inj_scatter[2 * idx + 1]; }
+  place_object(e, obj, P_GEN, idx, e->W, e->inj_scatter ? inj : NULL, rec);
+  e->last_scatter[2 * idx] = rec[0]; e->last_scatter[2 * idx + 1] = rec[1];
+  if (ox) { *ox = rec[0]; *oy = rec[1]; }
+}
+
+/* MeetupEnv.get_dist (meetup.py:78-84): Manhattan distance of every agent to the goal whose summed
+ * distance over the agents is smallest (np.argmin: the first such goal) */
+static void meetup_dist(const mgo_env* e, int* out) {
+  int best = 0, best_sum = 0;
+  for (int i = 0; i < e->n_goals; ++i) {
+    int sum = 0;
+    for (int j = 0; j < e->A; ++j) sum += abs(e->goal_x[i] - e->ax[j]) + abs(e->goal_y[i] - e->ay[j]);
+    if (i == 0 || sum < best_sum) { best = i; best_sum = sum; }
+  }
+  for (int j = 0; j < e->A; ++j) out[j] = abs(e->goal_x[best] - e->ax[j]) + abs(e->goal_y[best] - e->ay[j]);
+}
+
+/* ClutteredMultiGrid._gen_grid (multigrid_envs/cluttered.py:25-40) and MeetupEnv._gen_grid
+ * (multigrid_envs/meetup.py:64-76): border walls, then objects scattered by place_obj, then agents. */
+static void gen_scatter(mgo_env* e) {
+  const int W = e->W, H = e->H;
+  const obj_t wall = {T_WALL, C_GREY, 0, 0}, goal = {T_GOAL, C_GREEN, 0, 0}, lava = {T_LAVA, C_RED, 0, 0};
+  const obj_t door = {T_DOOR, C_RED, 2, 0};                       /* Door(color='red', is_locked=True) meetup.py:69 */
+  for (int j = 0; j < H; ++j)
+    for (int i = 0; i < W; ++i)
+      grid_set(&e->grid, i, j, (i == 0 || j == 0 || i == W - 1 || j == H - 1) ? wall : NONE);
+  int idx = 0;
+  if (e->kind == KIND_CLUTTERED) {
+    if (e->n_goals) place_scatter(e, goal, idx++, NULL, NULL);    /* cluttered.py:28-29 */
+    else grid_set(&e->grid, W - 2, H - 2, goal);                  /* cluttered.py:31 */
+    for (int c = 0; c < e->n_clutter; ++c) place_scatter(e, e->lava ? lava : wall, idx++, NULL, NULL);   /* :32-36 */
+  } else {
+    for (int i = 0; i < e->n_goals; ++i) place_scatter(e, door, idx++, &e->goal_x[i], &e->goal_y[i]);    /* meetup.py:67-70 */
+    for (int c = 0; c < e->n_clutter; ++c) place_scatter(e, wall, idx++, NULL, NULL);                   /* :71-72 */
+  }
+  e->n_scatter = idx;
+  e->spawn_w = W;
+  for (int a = 0; a < e->A; ++a) place_one_agent(e, a);           /* place_agent() cluttered.py:38 / meetup.py:74 */
+  if (e->kind == KIND_MEETUP) meetup_dist(e, e->past_dist);       /* MeetupEnv.reset meetup.py:59-62 */
+}
+
 static void do_reset(mgo_env* e, const int8_t* spawn, uint64_t t) {
   for (int a = 0; a < e->A; ++a) { e->has_pos[a] = 0; e->done[a] = 0; }   /* multigrid.py:471-473 */
   e->inj = spawn; e->purpose = P_SPAWN; e->t = t;
   if (e->kind == KIND_DOORKEY) gen_doorkey(e);
+  else if (e->kind == KIND_CLUTTERED || e->kind == KIND_MEETUP) gen_scatter(e);
   else {
     e->grid = e->base;                                   /* _gen_grid with the fixed seed */
     for (int a = 0; a < e->A; ++a) place_one_agent(e, a); /* cluttered.py:61-63 */
@@ -412,7 +479,26 @@ void mgo_reset_gen(mgo_env* e, const int8_t* spawn, const int8_t* gen /* [4] or 
   e->inj_gen = gen; do_reset(e, spawn, t); e->inj_gen = NULL;
 }
 
-void mgo_get_obs(const mgo_env* e, uint8_t* image /* [A][V*V*3] */, uint8_t* dir /* [A] */) {
+void mgo_reset_scatter(mgo_env* e, const int8_t* spawn, const int8_t* scatter /* [n_obj][2] or NULL */, uint64_t t) {
+  e->inj_gen = NULL; e->inj_scatter = scatter; do_reset(e, spawn, t); e->inj_scatter = NULL;
+}
+
+/* image: [A][obs_bytes].  fully_observed (multigrid.py:1043-1045): every agent gets Grid.encode() of
+ * the whole grid, [i][j][c] with the Agent objects in their cells, and its own direction. */
+void mgo_get_obs(const mgo_env* e, uint8_t* image, uint8_t* dir /* [A] */) {
+  if (e->full_obs) {
+    const int cb = e->W * e->H * 3;
+    for (int a = 0; a < e->A; ++a) {
+      for (int i = 0; i < e->W; ++i)
+        for (int j = 0; j < e->H; ++j) {
+          obj_t v = grid_get(&e->grid, i, j);
+          uint8_t* p = image + a * cb + (i * e->H + j) * 3;
+          if (v.type == T_NONE) { p[0] = T_EMPTY; p[1] = 0; p[2] = 0; } else { p[0] = v.type; p[1] = v.color; p[2] = v.state; }
+        }
+      dir[a] = (uint8_t)e->adir[a];
+    }
+    return;
+  }
   for (int a = 0; a < e->A; ++a) gen_agent_obs(e, a, image + a * e->V * e->V * 3, dir + a);
 }
 
@@ -617,6 +703,16 @@ void mgo_step_ex(mgo_env* e, const int* actions, const uint8_t* order, const int
     collective_done = s >= 1;
   }
   if (e->step_count >= e->max_steps) collective_done = 1;
+  if (e->kind == KIND_MEETUP) {                          /* MeetupEnv.step (meetup.py:86-95) */
+    int dist[MAXA], sum = 0;
+    meetup_dist(e, dist);
+    for (int a = 0; a < A; ++a) { rewards[a] = (double)(e->past_dist[a] - dist[a]); sum += dist[a]; }
+    if (sum == A) {
+      for (int a = 0; a < A; ++a) rewards[a] = rewards[a] + 1;
+      collective_done = 1;
+    }
+    for (int a = 0; a < A; ++a) e->past_dist[a] = dist[a];
+  }
 
   double shaped[MAXA];
   if (e->shaping == 1) shape_rewards(e, rewards, actions, shaped);
@@ -683,6 +779,20 @@ void mgo_last_gen(const mgo_env* e, int8_t* gen /* [4] */, int8_t* objdrop /* [A
   if (gen) memcpy(gen, e->last_gen, 4);
   if (objdrop) memcpy(objdrop, e->last_objdrop, (size_t)e->A * 4);
 }
+int mgo_last_scatter(const mgo_env* e, int8_t* out /* [MAXOBJ][2] */) {
+  memcpy(out, e->last_scatter, (size_t)e->n_scatter * 2);
+  return e->n_scatter;
+}
+/* kind-specific state in the product's packing (mg_buffers.aux, 4 words per env): words 0..2 = goal k
+ * (x | y<<6, 0xFFFFFFFF if unused), word 3 = past_goal_dist, one byte per agent */
+void mgo_aux_words(const mgo_env* e, uint32_t* out /* [4] */) {
+  for (int i = 0; i < 3; ++i) out[i] = 0xFFFFFFFFu;
+  out[3] = 0;
+  if (e->kind == KIND_MEETUP) {
+    for (int i = 0; i < e->n_goals; ++i) out[i] = (uint32_t)e->goal_x[i] | ((uint32_t)e->goal_y[i] << 6);
+    for (int a = 0; a < e->A && a < 4; ++a) out[3] |= (uint32_t)e->past_dist[a] << (8 * a);
+  }
+}
 /* what the last step/reset drew: order[A], respawn[A][4], spawn[A][4] */
 void mgo_last_draws(const mgo_env* e, uint8_t* order, int8_t* respawn, int8_t* spawn) {
   if (order) memcpy(order, e->last_order, (size_t)e->A);
@@ -730,8 +840,8 @@ void mgo_batch_reset(mgo_env** envs, int64_t n, int64_t stride, const uint8_t* m
     if (spawn) for (int a = 0; a < e->A; ++a) memcpy(sp + 4 * a, spawn + ((int64_t)a * stride + i) * 4, 4);
     do_reset(e, spawn ? sp : NULL, t);
     if (image && dir) {
-      uint8_t img[MAXA * MAXV * MAXV * 3], d[MAXA];
-      int cb = e->V * e->V * 3;
+      uint8_t img[MAXA * MAXW * MAXW * 3], d[MAXA];
+      int cb = mgo_obs_bytes(e);
       mgo_get_obs(e, img, d);
       for (int a = 0; a < e->A; ++a) {
         memcpy(image + ((int64_t)a * stride + i) * cb, img + a * cb, (size_t)cb);
@@ -748,7 +858,7 @@ void mgo_batch_step(mgo_env** envs, int64_t n, int64_t stride, const uint8_t* ac
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
     mgo_env* e = envs[i];
-    int A = e->A, act[MAXA], cb = e->V * e->V * 3;
+    int A = e->A, act[MAXA], cb = mgo_obs_bytes(e);
     uint8_t ord[MAXA]; int8_t rs[MAXA * 4], sp[MAXA * 4];
     if (actions) for (int a = 0; a < A; ++a) act[a] = actions[(int64_t)a * stride + i];
     else mgo_random_actions(e, t, act);
@@ -756,7 +866,7 @@ void mgo_batch_step(mgo_env** envs, int64_t n, int64_t stride, const uint8_t* ac
     if (order) for (int k = 0; k < A; ++k) ord[k] = order[(int64_t)k * stride + i];
     if (respawn) for (int a = 0; a < A; ++a) memcpy(rs + 4 * a, respawn + ((int64_t)a * stride + i) * 4, 4);
     if (reset_spawn) for (int a = 0; a < A; ++a) memcpy(sp + 4 * a, reset_spawn + ((int64_t)a * stride + i) * 4, 4);
-    uint8_t img[MAXA * MAXV * MAXV * 3], d[MAXA], dn;
+    uint8_t img[MAXA * MAXW * MAXW * 3], d[MAXA], dn;
     double rw[MAXA], er[MAXA];
     mgo_step(e, act, order ? ord : NULL, respawn ? rs : NULL, reset_spawn ? sp : NULL, t,
              image ? img : NULL, image ? d : NULL, rw, er, &dn);
@@ -782,8 +892,8 @@ void mgo_batch_reset_ex(mgo_env** envs, int64_t n, int64_t stride, const uint8_t
     if (spawn) for (int a = 0; a < e->A; ++a) memcpy(sp + 4 * a, spawn + ((int64_t)a * stride + i) * 4, 4);
     mgo_reset_gen(e, spawn ? sp : NULL, gen ? gen + i * 4 : NULL, t);
     if (image && dir) {
-      uint8_t img[MAXA * MAXV * MAXV * 3], d[MAXA];
-      int cb = e->V * e->V * 3;
+      uint8_t img[MAXA * MAXW * MAXW * 3], d[MAXA];
+      int cb = mgo_obs_bytes(e);
       mgo_get_obs(e, img, d);
       for (int a = 0; a < e->A; ++a) {
         memcpy(image + ((int64_t)a * stride + i) * cb, img + a * cb, (size_t)cb);
@@ -800,7 +910,7 @@ void mgo_batch_step_ex(mgo_env** envs, int64_t n, int64_t stride, const uint8_t*
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
     mgo_env* e = envs[i];
-    int A = e->A, act[MAXA], cb = e->V * e->V * 3;
+    int A = e->A, act[MAXA], cb = mgo_obs_bytes(e);
     uint8_t ord[MAXA]; int8_t rs[MAXA * 4], sp[MAXA * 4], od[MAXA * 4];
     if (actions) for (int a = 0; a < A; ++a) act[a] = actions[(int64_t)a * stride + i];
     else mgo_random_actions(e, t, act);
@@ -809,7 +919,7 @@ void mgo_batch_step_ex(mgo_env** envs, int64_t n, int64_t stride, const uint8_t*
     if (respawn) for (int a = 0; a < A; ++a) memcpy(rs + 4 * a, respawn + ((int64_t)a * stride + i) * 4, 4);
     if (objdrop) for (int a = 0; a < A; ++a) memcpy(od + 4 * a, objdrop + ((int64_t)a * stride + i) * 4, 4);
     if (reset_spawn) for (int a = 0; a < A; ++a) memcpy(sp + 4 * a, reset_spawn + ((int64_t)a * stride + i) * 4, 4);
-    uint8_t img[MAXA * MAXV * MAXV * 3], d[MAXA], dn;
+    uint8_t img[MAXA * MAXW * MAXW * 3], d[MAXA], dn;
     double rw[MAXA], er[MAXA];
     mgo_step_ex(e, act, order ? ord : NULL, respawn ? rs : NULL, objdrop ? od : NULL, reset_spawn ? sp : NULL,
                 reset_gen ? reset_gen + i * 4 : NULL, t, image ? img : NULL, image ? d : NULL, rw, er, &dn);
@@ -830,5 +940,36 @@ void mgo_batch_dyn_state(mgo_env** envs, int64_t n, int64_t stride, uint32_t* ca
   for (int64_t i = 0; i < n; ++i) {
     carry[i] = mgo_carry_word(envs[i]);
     mgo_grid_kinds(envs[i], kinds + i * envs[i]->W * envs[i]->H);
+  }
+}
+
+/* scatter kinds: batched reset with the scattered objects' accepted positions injected
+ * (scatter int8[stride][n_obj][2], or NULL -> Philox), aux state and recorder getters */
+void mgo_batch_reset_scatter(mgo_env** envs, int64_t n, int64_t stride, const uint8_t* mask, const int8_t* spawn,
+                             const int8_t* scatter, int n_obj, uint64_t t, uint8_t* image, uint8_t* dir) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    mgo_env* e = envs[i];
+    if (mask && !mask[i]) continue;
+    int8_t sp[MAXA * 4];
+    if (spawn) for (int a = 0; a < e->A; ++a) memcpy(sp + 4 * a, spawn + ((int64_t)a * stride + i) * 4, 4);
+    mgo_reset_scatter(e, spawn ? sp : NULL, scatter ? scatter + i * n_obj * 2 : NULL, t);
+    if (image && dir) {
+      uint8_t img[MAXA * MAXW * MAXW * 3], d[MAXA];
+      int cb = mgo_obs_bytes(e);
+      mgo_get_obs(e, img, d);
+      for (int a = 0; a < e->A; ++a) {
+        memcpy(image + ((int64_t)a * stride + i) * cb, img + a * cb, (size_t)cb);
+        dir[(int64_t)a * stride + i] = d[a];
+      }
+    }
+  }
+}
+
+void mgo_batch_aux(mgo_env** envs, int64_t n, uint32_t* aux /* [n][4] */, int8_t* scatter /* [n][n_obj][2] or NULL */, int n_obj) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    mgo_aux_words(envs[i], aux + i * 4);
+    if (scatter) memcpy(scatter + i * n_obj * 2, envs[i]->last_scatter, (size_t)n_obj * 2);
   }
 }

@@ -491,6 +491,86 @@ class PyDoorKeyEnv(PyRefEnv):
     return super().place_one_agent(agent_id, agent_obj=agent_obj, size=size)
 
 
+class PyClutteredEnv(PyRefEnv):
+  """ClutteredMultiGrid with a fresh layout per reset (multigrid_envs/cluttered.py:13-45): border walls,
+  goal (random or at (w-2,h-2)), n_clutter walls or lava scattered by place_obj, agents anywhere."""
+
+  def __init__(self, size=15, n_agents=3, n_clutter=25, randomize_goal=True, view_size=5, max_steps=250,
+               walls_are_lava=False, **kw):
+    self.size, self.n_clutter, self.randomize_goal, self.walls_are_lava = size, n_clutter, randomize_goal, walls_are_lava
+    super().__init__(np.zeros((size, size, 3), np.uint8), n_agents=n_agents, view_size=view_size, max_steps=max_steps, **kw)
+
+  def _wall_rect(self):
+    w = h = self.size
+    self.grid = CellGrid(w, h)
+    for i in range(w):
+      self.grid.set(i, 0, Wall())
+      self.grid.set(i, h - 1, Wall())
+    for j in range(h):
+      self.grid.set(0, j, Wall())
+      self.grid.set(w - 1, j, Wall())
+
+  def _gen_grid(self):
+    self._wall_rect()                                                    # cluttered.py:26-27
+    if self.randomize_goal:
+      self.place_obj(Goal())                                             # :28-29
+    else:
+      self.grid.set(self.size - 2, self.size - 2, Goal())               # :30-31
+    for _ in range(self.n_clutter):                                      # :32-36
+      self.place_obj(Lava() if self.walls_are_lava else Wall())
+    for a in range(self.n_agents):                                       # :38
+      self.place_one_agent(a)
+
+
+class PyMeetupEnv(PyClutteredEnv):
+  """MeetupEnv (multigrid_envs/meetup.py:26-95): n_goals locked red doors as meeting points, fully
+  observed, reward = decrease of the Manhattan distance to the jointly closest goal, +1 and done
+  when every agent stands next to it."""
+
+  def __init__(self, size=15, n_agents=3, n_goals=3, n_clutter=0, max_steps=250, **kw):
+    self.n_goals = n_goals
+    self.goal_pos = [None] * n_goals
+    self.past_goal_dist = None
+    super().__init__(size=size, n_agents=n_agents, n_clutter=n_clutter, max_steps=max_steps, **kw)
+
+  def reset(self):                                                       # meetup.py:59-62
+    obs = super().reset()
+    self.past_goal_dist = self.get_dist()
+    return obs
+
+  def _gen_grid(self):                                                   # meetup.py:64-76
+    self._wall_rect()
+    for i in range(self.n_goals):
+      self.goal_pos[i] = self.place_obj(Door('red', is_locked=True))
+    for _ in range(self.n_clutter):
+      self.place_obj(Wall())
+    for a in range(self.n_agents):
+      self.place_one_agent(a)
+
+  def get_dist(self):                                                    # meetup.py:78-84
+    dist = np.zeros((self.n_agents, self.n_goals))
+    for i, goal in enumerate(self.goal_pos):
+      for j, agent in enumerate(self.agent_pos):
+        dist[j, i] = np.sum(np.abs(goal - agent))
+    goal_dist = np.sum(dist, axis=0)
+    return dist[:, np.argmin(goal_dist)]
+
+  def step(self, actions):                                               # meetup.py:86-95
+    obs, _, done, info = super().step(actions)
+    goal_dist = self.get_dist()
+    reward = (self.past_goal_dist - goal_dist).tolist()
+    if np.sum(goal_dist) == self.n_agents:
+      reward = [r + 1 for r in reward]
+      done = True
+    self.past_goal_dist = goal_dist
+    return obs, reward, done, info
+
+  def gen_obs(self):                                                     # fully_observed, multigrid.py:1043-1065
+    image = self.grid.encode()
+    return {'image': [image.copy() for _ in range(self.n_agents)], 'direction': list(self.agent_dir),
+            'position': list(self.agent_pos)}
+
+
 class V8Shaper:
   """v8_robust_ppo.py:126-129, 159-220, 227-229."""
 

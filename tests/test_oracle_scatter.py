@@ -1,0 +1,145 @@
+"""Scatter generators: MeetupEnv (fully observed, distance reward, early done) and
+ClutteredMultiGrid with a fresh random layout per reset — C oracle against hand-derived answers and
+against the independent Python restatement fed the C oracle's recorded draws.  CPU only.
+Parity status: unpinned (no fixture for these envs in the reference).
+"""
+import numpy as np
+import pytest
+
+from oracle import c_oracle, py_ref_env
+from test_oracle_doorkey import Feed, py_grid, step_queue
+
+
+def layout_queue(scatter, spawn):
+  q = []
+  for x, y in scatter:
+    q += [int(x), int(y)]
+  for s in spawn:
+    q += [int(s[0]), int(s[1]), int(s[2])]
+  return q
+
+
+def test_meetup_known_answers():
+  """6x6, 2 agents, goals at (1,1) and (4,4): distances, argmin tie-breaking, the +1 / done rule."""
+  env = c_oracle.OracleEnv(None, W=6, H=6, A=2, V=7, max_steps=50, kind='meetup', n_goals=2, n_clutter=1)
+  obs = env.reset(spawn=[(2, 1, 0), (3, 4, 2)], scatter=[(1, 1), (4, 4), (3, 3)])
+  assert env.errors() == 0
+  img = obs['image'][0]
+  assert img.shape == (6, 6, 3) and np.array_equal(obs['image'][0], obs['image'][1])
+  assert tuple(img[1, 1]) == (4, 0, 2) and tuple(img[4, 4]) == (4, 0, 2) and tuple(img[3, 3]) == (2, 5, 0)
+  assert tuple(img[2, 1]) == (10, 0, 0) and tuple(img[3, 4]) == (10, 1, 2) and tuple(img[2, 2]) == (1, 0, 0)
+  # goal 0: |1-2|+0 + |1-3|+|1-4| = 1 + 5 = 6; goal 1: 2+3 + 1+0 = 6 -> tie, argmin takes goal 0
+  aux = env.aux_words()
+  assert aux[0] == 1 | 1 << 6 and aux[1] == 4 | 4 << 6 and aux[2] == 0xFFFFFFFF
+  assert aux[3] == 1 | 5 << 8
+  # agent 1 steps west to (2,4): goal 0 sum = 1 + (1+3) = 5, goal 1 sum = 5 + 2 = 7 -> goal 0; reward = 5 - 4
+  _, rew, done, _ = env.step([6, 2], order=[0, 1], respawn=[(-1, -1, 0)] * 2)
+  assert list(env.env_rewards) == [0.0, 1.0] and not done
+  # agent 0 turns left (faces north), agent 1 turns right (faces north): no change in distance
+  env.step([0, 1], order=[1, 0], respawn=[(-1, -1, 0)] * 2)
+  assert list(env.env_rewards) == [0.0, 0.0]
+  # agent 1 walks north three times: (2,3), (2,2); (2,1) is agent 0's cell -> blocked
+  for want in ([0.0, 1.0], [0.0, 1.0], [0.0, 0.0]):
+    env.step([6, 2], order=[0, 1], respawn=[(-1, -1, 0)] * 2)
+    assert list(env.env_rewards) == want
+  assert [tuple(p) for p in env.agent_pos] == [(2, 1), (2, 2)]
+  # agent 1 west to (1,2): distances 1 and 1 -> sum == n_agents: +1 each and done
+  env.step([6, 0], order=[0, 1], respawn=[(-1, -1, 0)] * 2)     # face west
+  _, rew, done, _ = env.step([6, 2], order=[0, 1], respawn=[(-1, -1, 0)] * 2)
+  assert list(env.env_rewards) == [1.0, 2.0] and done
+  # toggling the locked red door without a key changes nothing (multigrid.py:112-119)
+  env.step([6, 3], order=[0, 1], respawn=[(-1, -1, 0)] * 2)
+  env.step([6, 5], order=[0, 1], respawn=[(-1, -1, 0)] * 2)
+  assert tuple(env.grid()[1, 1]) == (4, 0, 2)
+
+
+def _cross(kind, size, A, steps, seed, max_steps, **gen):
+  rng = np.random.default_rng(seed)
+  okw = dict(n_goals=gen.get('n_goals', 1 if gen.get('randomize_goal', True) else 0), n_clutter=gen['n_clutter'],
+             lava=gen.get('walls_are_lava', False))
+  V = gen.get('view_size', 5)
+  c = c_oracle.OracleEnv(None, W=size, H=size, A=A, V=V, max_steps=max_steps, kind=kind, seed=seed, gid=3 * seed + 2, **okw)
+  feed = Feed()
+
+  def after_reset():
+    _, _, spawn = c.last_draws()
+    return layout_queue(c.last_scatter(), spawn)
+
+  c.reset()
+  feed.q = after_reset()
+  if kind == 'meetup':
+    py = py_ref_env.PyMeetupEnv(size=size, n_agents=A, n_goals=gen['n_goals'], n_clutter=gen['n_clutter'],
+                                max_steps=max_steps, rand_int=feed.rand_int, order_fn=lambda: feed.order)
+  else:
+    py = py_ref_env.PyClutteredEnv(size=size, n_agents=A, n_clutter=gen['n_clutter'], view_size=V, max_steps=max_steps,
+                                   randomize_goal=gen.get('randomize_goal', True), walls_are_lava=gen.get('walls_are_lava', False),
+                                   rand_int=feed.rand_int, order_fn=lambda: feed.order)
+  assert not feed.q
+  ev = dict(episodes=0, reward=0, early=0, deaths=0)
+
+  def compare(tag):
+    assert np.array_equal(c.grid(), py_grid(py)), tag
+    co, po = c._obs(), py.gen_obs()
+    for a in range(A):
+      assert np.array_equal(co['image'][a], po['image'][a]), (tag, a)
+      assert co['direction'][a] == po['direction'][a], (tag, a)
+
+  compare('reset')
+  for t in range(steps):
+    acts = [int(v) for v in rng.choice(7, size=A, p=[.15, .15, .4, .075, .075, .075, .075])]
+    obs, rew, done, _ = c.step(acts)
+    assert c.errors() == 0
+    order, respawn, _ = c.last_draws()
+    _, objdrop = c.last_gen()
+    feed.order = [int(o) for o in order]
+    feed.q = step_queue(feed.order, respawn, objdrop)
+    pobs, prew, pdone, _ = py.step(acts)
+    assert not feed.q
+    assert [float(r) for r in prew] == list(c.env_rewards) and bool(pdone) == done, (t, prew, c.env_rewards)
+    compare(t)
+    ev['reward'] += sum(1 for r in c.env_rewards if r != 0)
+    ev['deaths'] += int((respawn[:, 0] >= 0).sum())
+    if done:
+      ev['episodes'] += 1
+      ev['early'] += int(c.step_state() & 0xFFFF) < max_steps
+      c.reset()
+      feed.q = after_reset()
+      py.reset()
+      assert not feed.q
+      compare('reset after %d' % t)
+  return ev
+
+
+def test_meetup_cross_6x6():
+  ev = _cross('meetup', 6, 3, 3000, seed=2, max_steps=60, n_goals=3, n_clutter=0)
+  assert ev['episodes'] > 20 and ev['reward'] > 200 and ev['early'] > 0, ev
+
+
+def test_meetup_cross_8x8_clutter_single_goal():
+  ev = _cross('meetup', 8, 3, 1500, seed=4, max_steps=80, n_goals=1, n_clutter=5)
+  assert ev['episodes'] > 10 and ev['reward'] > 100, ev
+
+
+def test_cluttered_random_layout_cross():
+  ev = _cross('cluttered', 15, 3, 1500, seed=6, max_steps=60, n_clutter=25, randomize_goal=True)
+  assert ev['episodes'] > 15, ev
+
+
+def test_cluttered_lava_small_cross():
+  ev = _cross('cluttered', 6, 1, 3000, seed=8, max_steps=50, n_clutter=4, randomize_goal=False, walls_are_lava=True)
+  assert ev['episodes'] > 40 and ev['deaths'] > 20 and ev['reward'] > 0, ev
+
+
+def test_scatter_generator_statistics():
+  """Every scattered object lands on a distinct interior cell; goal position is uniform-ish over the interior."""
+  seen = set()
+  for gid in range(400):
+    env = c_oracle.OracleEnv(None, W=8, H=8, A=2, V=5, max_steps=50, kind='cluttered', n_goals=1, n_clutter=6, seed=5, gid=gid)
+    env.reset()
+    sc = env.last_scatter()
+    assert len(sc) == 7 and len({(int(x), int(y)) for x, y in sc}) == 7
+    assert all(1 <= x <= 6 and 1 <= y <= 6 for x, y in sc)
+    g = env.grid()
+    assert tuple(g[sc[0][1], sc[0][0]]) == (8, 1, 0) and int((g[:, :, 0] == 2).sum()) == 28 + 6
+    seen.add((int(sc[0][0]), int(sc[0][1])))
+  assert len(seen) == 36
