@@ -63,9 +63,20 @@ extern "C" {
  *             floor tiles gives every env its own mutable copy (the "mutable-grid" kernel below).
  *   DOORKEY = DoorKeyEnv._gen_grid (multigrid_envs/doorkey.py:34-86) drawn on device per env and per
  *             reset: border walls, goal at (W-2,H-2), a wall column at a random split with a locked
- *             yellow door, agents and a yellow key left of it.  No map upload; W == H >= 5. */
-#define MG_KIND_STATIC  0
-#define MG_KIND_DOORKEY 1
+ *             yellow door, agents and a yellow key left of it.  No map upload; W == H >= 5.
+ *   CLUTTERED = ClutteredMultiGrid._gen_grid (multigrid_envs/cluttered.py:25-40) drawn on device per env and
+ *             per reset: border walls, a goal (scattered when gen_n_goals = 1 = randomize_goal, at (W-2,H-2)
+ *             when 0), gen_n_clutter walls (lava with MG_GEN_LAVA) scattered by place_obj, agents anywhere.
+ *   MEETUP  = MeetupEnv (multigrid_envs/meetup.py:26-95): gen_n_goals (1..3) locked red doors as meeting
+ *             points and gen_n_clutter walls scattered, fully observed (obs = the whole encoded grid,
+ *             mg_buffers.obs_full, multigrid.py:1043-1045), reward = decrease of the Manhattan distance to the
+ *             jointly closest goal, +1 and done when every agent stands next to it (meetup.py:78-95). */
+#define MG_KIND_STATIC    0
+#define MG_KIND_DOORKEY   1
+#define MG_KIND_CLUTTERED 2
+#define MG_KIND_MEETUP    3
+#define MG_GEN_LAVA 1      /* gen_flags: Cluttered walls_are_lava */
+#define MG_MAX_SCATTER 64  /* gen_n_goals + gen_n_clutter */
 
 /* One-byte cell kind of the mutable per-env grids (mg_buffers.grid, carried objects):
  * 0 = nothing, door = 128 + color*4 + state, any other object = type*8 + color.  Agents are not
@@ -115,6 +126,10 @@ typedef struct mg_config {
   int64_t env_id_base;       /* global id of local env 0; Philox streams are keyed by the
                                 global id so results do not depend on the sharding */
   uint64_t seed;             /* Philox key for free-running mode */
+  int32_t gen_n_goals;       /* CLUTTERED: 1 = randomize_goal (cluttered.py:28-31); MEETUP: n_goals (meetup.py:32) */
+  int32_t gen_n_clutter;     /* n_clutter (cluttered.py:16, meetup.py:33) */
+  int32_t gen_flags;         /* MG_GEN_* */
+  int32_t reserved1;
 } mg_config;
 
 typedef struct mg_buffers {
@@ -144,6 +159,14 @@ typedef struct mg_buffers {
                             LDS address is linear in the cell index; use mg_export_grid for a plain [n][H*W] copy. */
   int32_t  grid_words;   /* ceil(W*H/4) */
   int32_t  mutable_grid;
+  uint32_t* aux;         /* MEETUP only, [env_stride][4]: words 0..2 = MeetupEnv.goal_pos[k] as x | y<<6 (0xFFFFFFFF if
+                            unused), word 3 = past_goal_dist, one byte per agent (meetup.py:61,70,94) */
+  uint8_t* obs_full;     /* fully observed kinds (MEETUP) only, [env_stride][W*H*3]: Grid.encode() of the whole grid,
+                            [x][y][(type,color,state)] with the agents in their cells as (10, id, dir); the same image
+                            for every agent (multigrid.py:1043-1045), obs['position'][a] is in env_state.  obs_image is
+                            NULL for these kinds. */
+  int32_t  obs_full_bytes;
+  int32_t  reserved2;
 } mg_buffers;
 
 typedef struct mg_handle mg_handle;
@@ -198,6 +221,12 @@ int mg_step_replay(mg_handle* h, const void* actions, const uint8_t* order,
 int mg_reset_inject_dyn(mg_handle* h, const uint8_t* env_mask, const int8_t* spawn, const int8_t* gen);
 int mg_step_replay_dyn(mg_handle* h, const void* actions, const uint8_t* order, const int8_t* respawn,
                        const int8_t* objdrop, const int8_t* reset_spawn, const int8_t* reset_gen);
+
+/* Reset of the scatter kinds (CLUTTERED, MEETUP) with the layout the reference drew injected: scatter = device
+ * int8[env_stride][gen_n_goals + gen_n_clutter][2] = the (x, y) place_obj accepted for every scattered object in
+ * draw order (goal / goal doors first, then the clutter; cluttered.py:28-36, meetup.py:67-72); spawn as in
+ * mg_reset_inject.  Either pointer may be NULL (drawn on device).  Auto-resets inside step always draw on device. */
+int mg_reset_inject_scatter(mg_handle* h, const uint8_t* env_mask, const int8_t* spawn, const int8_t* scatter);
 
 /* env.grid as plain per-env arrays (multigrid.py:281-319 Grid.grid minus the Agent objects):
  * out = device uint8[n_envs][H*W], out[n][y*W+x] = kind id.  Mutable-grid handles only. */

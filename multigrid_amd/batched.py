@@ -33,9 +33,12 @@ class BatchedMultiGrid:
   def __init__(self, cells, n_envs, n_agents=3, view_size=5, max_steps=100, see_through_walls=False,
                competitive=False, shaping='v8', auto_reset=True, device=0, seed=0,
                env_id_base=0, emit_env_reward=False, use_torch_stream=True, kernel_path='auto',
-               kind='static', size=None):
+               kind='static', size=None, n_goals=0, n_clutter=0, walls_are_lava=False):
     """kind='static': `cells` uint8[H, W, 3] is the layout every reset starts from (objects allowed).
-    kind='doorkey': `cells` is None and `size` the grid size; layouts are drawn on device."""
+    kind='doorkey' | 'cluttered' | 'meetup': `cells` is None and `size` the grid size; layouts are drawn
+    on device per env and per reset.  cluttered: n_goals = 1 for randomize_goal (0: goal at (size-2, size-2)),
+    n_clutter obstacles (lava with walls_are_lava); meetup: n_goals goal doors (1..3), n_clutter walls,
+    fully observed (`obs_full`, `obs_image` is None)."""
     self.L = _lib.load()
     self.kind = kind
     if kind == 'static':
@@ -52,8 +55,8 @@ class BatchedMultiGrid:
         width=self.width, height=self.height, n_agents=n_agents, view_size=view_size, max_steps=max_steps,
         see_through_walls=int(see_through_walls), competitive=int(competitive),
         shaping_kind={None: 0, 'none': 0, 'v8': 1}[shaping], auto_reset=int(auto_reset),
-        env_kind={'static': _lib.KIND_STATIC, 'doorkey': _lib.KIND_DOORKEY}[kind],
-        emit_env_reward=int(emit_env_reward),
+        env_kind=_lib.KINDS[kind], emit_env_reward=int(emit_env_reward),
+        gen_n_goals=int(n_goals), gen_n_clutter=int(n_clutter), gen_flags=_lib.GEN_LAVA if walls_are_lava else 0,
         kernel_path={'auto': 0, 'generic': 1, 'table': 2}[kernel_path],
         n_envs=n_envs, env_id_base=env_id_base, seed=seed)
     self.h = C.c_void_p()
@@ -70,13 +73,17 @@ class BatchedMultiGrid:
     self.stride = S = int(b.env_stride)
     A, V, n, dev = self.n_agents, self.view_size, self.n_envs, self.device
     # full-stride tensors (what the kernels address) ...
-    self._obs_image = _alias(b.obs_image, (A, S, V, V, 3), '|u1', dev)
+    self._obs_image = _alias(b.obs_image, (A, S, V, V, 3), '|u1', dev) if b.obs_image else None
+    self._obs_full = _alias(b.obs_full, (S, self.width, self.height, 3), '|u1', dev) if b.obs_full else None
     self._dir_done = _alias(b.dir_done, (S, int(b.dir_done_bytes)), '|u1', dev)
     self._reward = _alias(b.reward, (A, S), '<f8', dev)
     self._env_reward = _alias(b.env_reward, (A, S), '<f8', dev) if b.env_reward else None
     self._env_state = _alias(b.env_state, (S, A + 1), '<i4', dev)
     # ... and the [:, :n_envs] views callers use
-    self.obs_image = self._obs_image[:, :n]      # obs['image'][a]     uint8[A, N, V, V, 3]
+    self.obs_image = None if self._obs_image is None else self._obs_image[:, :n]   # obs['image'][a] uint8[A, N, V, V, 3]
+    # fully observed kinds: obs['image'][a] is the same whole-grid encoding for every a, uint8[N, W, H, 3]
+    self.obs_full = None if self._obs_full is None else self._obs_full[:n]
+    self.aux = _alias(b.aux, (S, 4), '<i4', dev)[:n] if b.aux else None         # packing in include/mgrid.h
     self.obs_dir = self._dir_done[:n, :A].t()    # obs['direction'][a] uint8[A, N] (strided view)
     self.reward = self._reward[:, :n]            # rewards[a]          float64[A, N]
     self.env_reward = None if self._env_reward is None else self._env_reward[:, :n]
@@ -141,6 +148,8 @@ class BatchedMultiGrid:
     return self._env_major(t, torch.uint8, 4)
 
   def obs(self):
+    if self.obs_full is not None:      # fully_observed (multigrid.py:1043-1065)
+      return {'image': [self.obs_full] * self.n_agents, 'direction': self.obs_dir, 'position': self.agent_pos}
     return {'image': self.obs_image, 'direction': self.obs_dir}
 
   @property
@@ -191,11 +200,21 @@ class BatchedMultiGrid:
     g = g.contiguous()
     return C.c_void_p(g.data_ptr()), g
 
-  def reset(self, mask=None, spawn=None, gen=None):
+  def reset(self, mask=None, spawn=None, gen=None, scatter=None):
     """env.reset() for all envs (or those in `mask`).  spawn: int8[A, N, 4] (x,y,dir,0) to inject;
-    gen: int8[N, 4] (split, door, key_x, key_y) DoorKey layout draws to inject."""
+    gen: int8[N, 4] (split, door, key_x, key_y) DoorKey layout draws to inject; scatter: int8[N, n_obj, 2]
+    accepted (x, y) of the scattered objects of a cluttered / meetup layout."""
     mp, _m = self._mask_ptr(mask)
-    if gen is not None or (spawn is not None and self.mutable_grid):
+    if scatter is not None:
+      sp, _s = self._env_major(spawn, torch.int8, self.n_agents, (4,))
+      sc = torch.as_tensor(scatter, device=self.device).to(torch.int8)
+      if sc.shape[0] != self.stride:
+        buf = torch.zeros((self.stride,) + tuple(sc.shape[1:]), dtype=torch.int8, device=self.device)
+        buf[:sc.shape[0]] = sc
+        sc = buf
+      sc = sc.contiguous()
+      _lib.check(self.L.mg_reset_inject_scatter(self.h, mp, sp, C.c_void_p(sc.data_ptr())))
+    elif gen is not None or (spawn is not None and self.mutable_grid):
       sp, _s = self._env_major(spawn, torch.int8, self.n_agents, (4,))
       gp, _g = self._gen_ptr(gen)
       _lib.check(self.L.mg_reset_inject_dyn(self.h, mp, sp, gp))

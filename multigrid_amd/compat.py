@@ -66,8 +66,12 @@ class RefCompatEnv:
     self.grid = _LiveGridView(batched) if batched.mutable_grid else _GridView(batched.cells)
 
   def _obs(self):
-    img = self.b.obs_image[:, 0].cpu().numpy()
     d = self.b.obs_dir[:, 0].cpu().numpy()
+    if self.b.obs_full is not None:            # fully_observed (multigrid.py:1043-1065)
+      full = self.b.obs_full[0].cpu().numpy()
+      return {'image': [full.copy() for _ in range(self.n_agents)], 'direction': [int(x) for x in d],
+              'position': self.agent_pos}
+    img = self.b.obs_image[:, 0].cpu().numpy()
     return {'image': [img[a] for a in range(self.n_agents)], 'direction': [int(x) for x in d]}
 
   def reset(self):

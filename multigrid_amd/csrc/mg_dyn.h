@@ -26,6 +26,8 @@ constexpr uint32_t K_WALL = MG_T_WALL * 8 + 5;                 // grey wall: wal
 constexpr uint32_t K_GOAL = MG_T_GOAL * 8 + 1;                 // green goal
 constexpr uint32_t K_DOOR_YELLOW_LOCKED = 128 + 4 * 4 + 2;     // Door('yellow', is_locked=True), doorkey.py:60
 constexpr uint32_t K_KEY_YELLOW = MG_T_KEY * 8 + 4;            // Key('yellow'), doorkey.py:65
+constexpr uint32_t K_DOOR_RED_LOCKED = 128 + 0 * 4 + 2;        // Door(color='red', is_locked=True), meetup.py:69
+constexpr uint32_t K_LAVA = MG_T_LAVA * 8 + 0;                 // red lava
 enum { P_GEN = 4, P_KEY = 5, P_OBJDROP = 6 };
 
 // kind id -> encode() triple (type | color<<8 | state<<16) + behaviour flags.  256 entries, built
@@ -148,6 +150,7 @@ template <int A>
 struct DynIn {
   uint32_t st[4];           // env_state words (A + 1 used)
   uint32_t carry, act;
+  uint32_t aux[4];          // MEETUP: goal positions and past distances
   uint32_t pre[kPreMax];    // this lane's share of the chunk's grid rows (dword lane + 64k), GW <= kPreMax only
 };
 
@@ -161,6 +164,11 @@ __device__ __forceinline__ void dyn_load(const Params& p, int64_t env0, int lane
   in.carry = asm_load_u32(p.carry + n);
   in.act = 0x06060606u;
   if (p.op == OP_STEP && !p.random_actions) in.act = asm_load_u32(p.actions + n);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    in.aux[k] = 0u;
+    if (p.aux) in.aux[k] = asm_load_u32(p.aux + n * 4 + k);
+  }
   const uint32_t* ghbm = p.grid + (env0 >> 6) * (int64_t)p.GW * kWave + lane;
 #pragma unroll
   for (int k = 0; k < kPreMax; ++k) {
@@ -172,14 +180,69 @@ __device__ __forceinline__ void dyn_load(const Params& p, int64_t env0, int lane
 template <int A, int K>
 __device__ __forceinline__ void dyn_wait(DynIn<A>& in) {
   static_assert(A <= 3 && kPreMax == 16, "operand list below");
-  asm volatile("s_waitcnt vmcnt(%22)"
+  asm volatile("s_waitcnt vmcnt(%26)"
                : "+v"(in.st[0]), "+v"(in.st[1]), "+v"(in.st[2]), "+v"(in.st[3]),
-                 "+v"(in.carry), "+v"(in.act),
+                 "+v"(in.carry), "+v"(in.act), "+v"(in.aux[0]), "+v"(in.aux[1]), "+v"(in.aux[2]), "+v"(in.aux[3]),
                  "+v"(in.pre[0]), "+v"(in.pre[1]), "+v"(in.pre[2]), "+v"(in.pre[3]), "+v"(in.pre[4]), "+v"(in.pre[5]),
                  "+v"(in.pre[6]), "+v"(in.pre[7]), "+v"(in.pre[8]), "+v"(in.pre[9]), "+v"(in.pre[10]), "+v"(in.pre[11]),
                  "+v"(in.pre[12]), "+v"(in.pre[13]), "+v"(in.pre[14]), "+v"(in.pre[15])
                : "n"(K)
                : "memory");
+}
+
+// MeetupEnv.get_dist (meetup.py:78-84): Manhattan distance of every agent to the goal whose summed
+// distance over the agents is smallest (np.argmin: the first such goal).  Returns one byte per agent.
+template <int A>
+__device__ __forceinline__ uint32_t meetup_dist(const Params& p, uint64_t pd, const uint32_t (&goal)[3], uint32_t& sum_out) {
+  uint32_t best = 0, best_sum = 0xFFFFFFFFu;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (i >= p.n_goals) continue;
+    const int gx = (int)(goal[i] & 63u), gy = (int)((goal[i] >> 6) & 63u);
+    uint32_t sum = 0, bytes = 0;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      const uint32_t me = pd_get(pd, a);
+      const uint32_t dd = (uint32_t)(abs(gx - aw_x(me)) + abs(gy - aw_y(me)));
+      sum += dd;
+      bytes |= dd << (8 * a);
+    }
+    if (sum < best_sum) { best_sum = sum; best = bytes; }
+  }
+  sum_out = best_sum;
+  return best;
+}
+
+// Fully observed obs (multigrid.py:1043-1045): Grid.encode() of the whole grid, [x][y][3] bytes, with
+// the agents in their cells as (10, id, dir).  Each lane writes its env's image into the wave's
+// staging area byte by byte; the 64 images then leave as one contiguous run of 16-byte vectors.
+template <int A>
+__device__ __forceinline__ void emit_full(const Params& p, const uint8_t* g, const uint32_t* lut, uint64_t pd,
+                                          uint32_t* stage, int lane, uint8_t* gchunk) {
+  const int FB = p.W * p.H * 3;
+  uint8_t* sb = reinterpret_cast<uint8_t*>(stage) + lane * FB;
+  for (int x = 0; x < p.W; ++x)
+    for (int y = 0; y < p.H; ++y) {
+      const uint32_t w = lut[g_get(g, g_off(p, x, y))];
+      uint8_t* q = sb + (x * p.H + y) * 3;
+      q[0] = (uint8_t)w; q[1] = (uint8_t)(w >> 8); q[2] = (uint8_t)(w >> 16);
+    }
+#pragma unroll
+  for (int b = 0; b < A; ++b) {
+    const uint32_t o = pd_get(pd, b);
+    uint8_t* q = sb + (aw_x(o) * p.H + aw_y(o)) * 3;
+    q[0] = (uint8_t)MG_T_AGENT; q[1] = (uint8_t)b; q[2] = (uint8_t)aw_d(o);   // Agent.encode multigrid.py:137-139
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int nv = 4 * FB;                        // 16-byte vectors in the 64-image chunk
+  const uint4* src = reinterpret_cast<const uint4*>(stage);
+  uint4* dst = reinterpret_cast<uint4*>(gchunk);
+  for (int idx = lane; idx < nv; idx += kWave) dst[idx] = src[idx];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // One chunk (64 envs) of one step()/reset() on mutable grids.
@@ -228,8 +291,10 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   }
   uint32_t st = in.st[A];
   uint32_t carry = in.carry;
+  uint32_t goal[3] = {in.aux[0], in.aux[1], in.aux[2]};       // MEETUP: goal_pos[k] = x | y<<6
+  uint32_t past = in.aux[3];                                  // MEETUP: past_goal_dist, one byte per agent
   // agents (re)spawn at x < spawn_w: the DoorKey split (doorkey.py:77-78), the whole grid otherwise
-  int spawn_w = p.kind == MG_KIND_STATIC ? p.W : (int)min((st >> 24) & 63u, (uint32_t)p.W);
+  int spawn_w = p.kind != MG_KIND_DOORKEY ? p.W : (int)min((st >> 24) & 63u, (uint32_t)p.W);
   uint32_t done_flag = 0;
 
   const bool is_step = p.op == OP_STEP;
@@ -320,13 +385,30 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 
     double rew[A], out_rew[A];
 #pragma unroll
-    for (int a = 0; a < A; ++a) {
-      rew[a] = ((gbits >> a) & 1u) ? rgoal : 0.0;
-      out_rew[a] = rew[a];
-      if (p.shaping == MG_SHAPING_V8)
-        shw[a] = v8_shape(p, dist, shw[a], pd_get(pd, a), (actw >> (3 * a)) & 7u, rew[a], out_rew[a]);
+    for (int a = 0; a < A; ++a) rew[a] = ((gbits >> a) & 1u) ? rgoal : 0.0;
+    if (p.kind == MG_KIND_MEETUP) {                                             // MeetupEnv.step, meetup.py:86-95
+      uint32_t sum;
+      const uint32_t cur = meetup_dist<A>(p, pd, goal, sum);
+      const bool met = sum == (uint32_t)A;
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        const int delta = (int)((past >> (8 * a)) & 255u) - (int)((cur >> (8 * a)) & 255u);
+        rew[a] = (double)(delta + (met ? 1 : 0));
+      }
+      if (met) done_flag = 1u;
+      past = cur;
     }
-    st = step | (dbits << 16) | (p.kind == MG_KIND_STATIC ? 0u : (uint32_t)spawn_w << 24);
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      out_rew[a] = rew[a];
+      if (p.shaping == MG_SHAPING_V8) {
+        // get_goal_position (v8:159-169): the per-env scattered goal of a Cluttered layout, else the handle's
+        const bool own = p.kind == MG_KIND_CLUTTERED && p.n_goals != 0;
+        const int gx = own ? (int)(goal[0] & 63u) : p.gx, gy = own ? (int)((goal[0] >> 6) & 63u) : p.gy;
+        shw[a] = v8_shape<true>(p, dist, shw[a], pd_get(pd, a), (actw >> (3 * a)) & 7u, rew[a], out_rew[a], gx, gy);
+      }
+    }
+    st = step | (dbits << 16) | (p.kind == MG_KIND_DOORKEY ? (uint32_t)spawn_w << 24 : 0u);
     if (active) {
 #pragma unroll
       for (int a = 0; a < A; ++a) {
@@ -358,6 +440,27 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       for (int j = 0; j < p.H; ++j) g_set(g, g_off(p, split, j), K_WALL);       // vert_wall(split_idx, 0)
       spawn_w = split;
     }
+    if (p.kind == MG_KIND_CLUTTERED || p.kind == MG_KIND_MEETUP) {
+      // place_obj for every scattered object in draw order (cluttered.py:28-36, meetup.py:67-72): the
+      // goal / goal doors first, then the clutter.  No agent has a position yet (multigrid.py:471-473).
+      const uint32_t k1 = p.kind == MG_KIND_MEETUP ? K_DOOR_RED_LOCKED : K_GOAL;
+      const uint32_t k2 = (p.kind == MG_KIND_CLUTTERED && (p.gen_flags & MG_GEN_LAVA)) ? K_LAVA : K_WALL;
+      const int n_obj = p.n_goals + p.n_clutter;
+      const bool inj = p.scatter != nullptr;
+#pragma unroll 1
+      for (int i = 0; i < n_obj; ++i) {
+        const uint32_t w = place_dyn<A>(p, g, pd, 0u, i, P_GEN, p.W, inj, inj ? (uint32_t)p.scatter[n * n_obj + i] : 0u, false, gid);
+        g_set(g, g_off(p, aw_x(w), aw_y(w)), i < p.n_goals ? k1 : k2);
+        err |= w >> 16;
+        if (i < p.n_goals) {                       // Meetup goal_pos[i]; Cluttered: the goal the shaper measures to
+          if (i == 0) goal[0] = w & AW_POS;
+          if (i == 1) goal[1] = w & AW_POS;
+          if (i == 2) goal[2] = w & AW_POS;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) if (i >= p.n_goals) goal[i] = 0xFFFFFFFFu;
+    }
 #pragma unroll 1
     for (int a = 0; a < A; ++a) {                                               // place_agent, in agent order
       const bool inj = p.reset_spawn != nullptr;
@@ -372,9 +475,13 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       g_set(g, g_off(p, aw_x(w), aw_y(w)), K_KEY_YELLOW);
       err |= w >> 16;
     }
+    if (p.kind == MG_KIND_MEETUP) {                                             // MeetupEnv.reset, meetup.py:59-62
+      uint32_t sum;
+      past = meetup_dist<A>(p, pd, goal, sum);
+    }
 #pragma unroll
     for (int a = 0; a < A; ++a) shw[a] = 0u;
-    st = p.kind == MG_KIND_STATIC ? 0u : (uint32_t)spawn_w << 24;
+    st = p.kind == MG_KIND_DOORKEY ? (uint32_t)spawn_w << 24 : 0u;
   }
 
   if (active) {
@@ -382,6 +489,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     for (int a = 0; a < A; ++a) p.env_state[n * (A + 1) + a] = shw[a] | pd_get(pd, a);
     p.env_state[n * (A + 1) + A] = st;
     p.carry[n] = carry;
+    if (p.aux) reinterpret_cast<uint4*>(p.aux)[n] = make_uint4(goal[0], goal[1], goal[2], past);
     uint64_t dd = (uint64_t)done_flag << (8 * A);
 #pragma unroll
     for (int a = 0; a < A; ++a) dd |= (uint64_t)aw_d(pd_get(pd, a)) << (8 * a);
@@ -401,12 +509,16 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 
   // ---- gen_obs (multigrid.py:1037-1067) --------------------------------------------------------
 #if MG_ABL != 2
+  if (p.full_obs) {
+    emit_full<A>(p, g, lut, pd, stage, lane, p.obs_full + env0 * (int64_t)(p.W * p.H * 3));
+  } else {
 #pragma unroll
-  for (int a = 0; a < A; ++a) {
-    uint32_t s[NW + 1];
-    uint64_t vm;
-    dyn_view<V>(p, g, lut, pd_get(pd, a), (carry >> (8 * a)) & 255u, s, vm);
-    emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB);
+    for (int a = 0; a < A; ++a) {
+      uint32_t s[NW + 1];
+      uint64_t vm;
+      dyn_view<V>(p, g, lut, pd_get(pd, a), (carry >> (8 * a)) & 255u, s, vm);
+      emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB);
+    }
   }
 #endif
 }
@@ -415,14 +527,15 @@ template <int A, int V>
 __global__ __launch_bounds__(256) void mg_dyn_kernel(const Params p) {
   constexpr int ROWB = ViewGeom<V>::ROWB;
   extern __shared__ __align__(16) uint8_t smem[];
-  // LDS carve: [stage: nw x 64*ROWB B][grids: nw x (W+2)(H+2)*68 B][dist LUT: W*H f64][kind LUT: 256 u32]
+  // LDS carve: [stage: nw x 64*ROWB B][grids: nw x (W+2)(H+2)*68 B][distance LUT: LW*LH f64][kind LUT: 256 u32]
   //            [base: GW u32][pidx: W*H u16]
   const int nw = blockDim.x >> 6;
   const int pcells = (p.W + 2) * (p.H + 2), cells = p.W * p.H;
   uint32_t* stage_all = reinterpret_cast<uint32_t*>(smem);
-  uint32_t* grids = reinterpret_cast<uint32_t*>(smem + (size_t)nw * kWave * ROWB);
+  const int stage_b = p.full_obs ? kWave * p.W * p.H * 3 : kWave * ROWB;    // per wave, a multiple of 64
+  uint32_t* grids = reinterpret_cast<uint32_t*>(smem + (size_t)nw * stage_b);
   double* dist = reinterpret_cast<double*>(grids + (size_t)nw * pcells * kCellW + ((nw * pcells * kCellW) & 1));
-  uint32_t* lut = reinterpret_cast<uint32_t*>(dist + cells);
+  uint32_t* lut = reinterpret_cast<uint32_t*>(dist + p.LW * p.LH);
   uint32_t* base = lut + 256;
   uint16_t* pidx = reinterpret_cast<uint16_t*>(base + p.GW);
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
@@ -436,15 +549,13 @@ __global__ __launch_bounds__(256) void mg_dyn_kernel(const Params p) {
 
   for (int i = tid; i < 256; i += blockDim.x) lut[i] = kind_word((uint32_t)i);
   for (int i = tid; i < p.GW; i += blockDim.x) base[i] = p.base_grid[i];
-  for (int i = tid; i < cells; i += blockDim.x) {
-    dist[i] = p.dist_lut[i];
-    pidx[i] = (uint16_t)((i / p.W + 1) * (p.W + 2) + (i % p.W) + 1);
-  }
+  for (int i = tid; i < p.LW * p.LH; i += blockDim.x) dist[i] = p.dist_lut[i];
+  for (int i = tid; i < cells; i += blockDim.x) pidx[i] = (uint16_t)((i / p.W + 1) * (p.W + 2) + (i % p.W) + 1);
   // every wave's padded grid starts as all grey wall: the ring is never written again
   for (int i = tid; i < nw * pcells * kCellW; i += blockDim.x) grids[i] = K_WALL * 0x01010101u;
   __syncthreads();
 
-  uint32_t* stage = stage_all + wv * (kWave * ROWB / 4);
+  uint32_t* stage = stage_all + wv * (stage_b / 4);
   uint32_t* gw = grids + (size_t)wv * pcells * kCellW;
   uint32_t err = 0;
   // vector-memory operations a chunk issues after the next chunk's prefetch, all of them for at
@@ -456,6 +567,7 @@ __global__ __launch_bounds__(256) void mg_dyn_kernel(const Params p) {
 #endif
   constexpr int kLo = (kObs + A + 3) < 63 ? (kObs + A + 3) : 63;               // + GW unknown at compile time
   constexpr int kHi = (kObs + A + 3 + 16) < 63 ? (kObs + A + 3 + 16) : 63;     // GW == 16 (8x8)
+  constexpr int kFull = A + 3;                                                 // fully observed: at least these
   if (c < p.n_chunks) dyn_wait<A, 0>(cur);
   for (; c < p.n_chunks; c += cstride) {
     const int64_t cn = c + cstride;
@@ -463,7 +575,9 @@ __global__ __launch_bounds__(256) void mg_dyn_kernel(const Params p) {
     if (more) dyn_load<A>(p, cn * kWave, lane, nxt);
     dyn_chunk<A, V>(p, dist, lut, base, pidx, stage, gw, lane, c * kWave, cur, err);
     if (more) {
-      if (p.GW == 16) dyn_wait<A, kHi>(nxt); else dyn_wait<A, kLo>(nxt);
+      if (p.full_obs) dyn_wait<A, kFull>(nxt);
+      else if (p.GW == 16) dyn_wait<A, kHi>(nxt);
+      else dyn_wait<A, kLo>(nxt);
       cur = nxt;
     }
   }

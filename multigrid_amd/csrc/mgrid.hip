@@ -93,6 +93,11 @@ struct Params {
   const uint32_t* reset_gen;   // int8x4 per env
   uint32_t* carry;             // [stride]
   uint32_t* grid;              // [n_chunks][GW][64]
+  int32_t n_goals, n_clutter, gen_flags, full_obs;   // scatter generators (CLUTTERED, MEETUP)
+  int32_t gx, gy, LW, LH;      // shaper goal and the dims of the mutable-grid kernel's |dx|,|dy| distance LUT
+  const uint16_t* scatter;     // int8x2 per (env, scattered object): injected layout draws
+  uint32_t* aux;               // [stride][4]  MEETUP goal positions + past distances
+  uint8_t* obs_full;           // [stride][W*H*3]  fully observed obs
 };
 
 struct U4 { uint32_t x, y, z, w; };
@@ -435,8 +440,12 @@ __device__ __forceinline__ uint32_t agent_order(const Params& p, int64_t n, uint
 // v8 shape_rewards for one agent (v8_robust_ppo.py:171-220), float64, one rounding per
 // operation.  w = the agent's shaper bits (prev_x, prev_y, valid, stationary), me = its post-step
 // position word, env_rew = its env reward.  Returns the new shaper bits.
+// REL = false: dist[y*W + x] = distance of cell (x, y) to the handle's one goal (shared-map kernels);
+// REL = true: dist[|dy|*LW + |dx|] = sqrt(dx^2 + dy^2), looked up relative to goal (gx, gy), which may
+// differ per env (mutable-grid kernel).  Both tables are built on the host with the same sqrt.
+template <bool REL = false>
 __device__ __forceinline__ uint32_t v8_shape(const Params& p, const double* dist, uint32_t w, uint32_t me, uint32_t act,
-                                             double env_rew, double& out) {
+                                             double env_rew, double& out, int gx = 0, int gy = 0) {
   if (env_rew > 0.0) {                            // goal touch: prev_* cleared, count 0 (v8:181-186)
     out = 5.0;
     return 0u;
@@ -446,9 +455,10 @@ __device__ __forceinline__ uint32_t v8_shape(const Params& p, const double* dist
   const bool has = (w >> 26) & 1u;
   const int px = (int)((w >> 14) & 63u), py = (int)((w >> 20) & 63u);
   uint32_t stat = (w >> 27) & 7u;
-  const double cur = dist[y * p.W + x];           // np.linalg.norm(pos - goal), v8:192
+  const double cur = REL ? dist[abs(y - gy) * p.LW + abs(x - gx)] : dist[y * p.W + x];   // np.linalg.norm(pos - goal), v8:192
   if (has) {
-    const double prev = dist[min(py, p.H - 1) * p.W + min(px, p.W - 1)];
+    const int qx = min(px, p.W - 1), qy = min(py, p.H - 1);
+    const double prev = REL ? dist[abs(qy - gy) * p.LW + abs(qx - gx)] : dist[qy * p.W + qx];
     r = r + (prev - cur) * 0.2;                   // v8:193-195
     if (px == x && py == y) {                     // v8:199-206
       stat = min(stat + 1u, 7u);                  // only "> 3" is ever tested: saturating is exact
@@ -801,6 +811,10 @@ struct mg_handle {
   uint32_t* base_grid;
   uint32_t* carry;
   uint32_t* grid;
+  uint32_t* aux;
+  uint8_t* obs_full;
+  bool full_obs;
+  int LW, LH;            // dims of the mutable-grid kernel's relative distance LUT
   mg_buffers buf;
   std::vector<void*> allocs;
 };
@@ -859,8 +873,8 @@ void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid
 // per CU as LDS allows; persistent over chunks.
 void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* lds_out) {
   const mg_config& c = h->cfg;
-  const size_t rowb = (size_t)c.view_size * c.view_size * 3;
-  const size_t fixed = ((size_t)c.width * c.height * 10 + 256 * 4 + (size_t)h->GW * 4 + 8 + 15) / 16 * 16;
+  const size_t rowb = h->full_obs ? (size_t)c.width * c.height * 3 : (size_t)c.view_size * c.view_size * 3;
+  const size_t fixed = ((size_t)h->LW * h->LH * 8 + (size_t)c.width * c.height * 2 + 256 * 4 + (size_t)h->GW * 4 + 8 + 15) / 16 * 16;
   const size_t per_wave = (size_t)kWave * rowb + (size_t)(c.width + 2) * (c.height + 2) * kCellB;
   int nw = 4;
   while (nw > 1 && (fixed + nw * per_wave > (size_t)kLdsLimit || h->n_chunks < (int64_t)h->n_cu * nw)) nw >>= 1;
@@ -875,7 +889,7 @@ void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* l
 
 int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, const int8_t* respawn,
            const int8_t* reset_spawn, const uint8_t* mask, int random_actions, uint8_t* actions_out,
-           const int8_t* objdrop = nullptr, const int8_t* reset_gen = nullptr) {
+           const int8_t* objdrop = nullptr, const int8_t* reset_gen = nullptr, const int8_t* scatter = nullptr) {
   Params p;
   memset(&p, 0, sizeof(p));
   const mg_config& c = h->cfg;
@@ -899,6 +913,9 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   p.objdrop = reinterpret_cast<const uint32_t*>(objdrop);
   p.reset_gen = reinterpret_cast<const uint32_t*>(reset_gen);
   p.carry = h->carry; p.grid = h->grid;
+  p.n_goals = c.gen_n_goals; p.n_clutter = c.gen_n_clutter; p.gen_flags = c.gen_flags; p.full_obs = h->full_obs ? 1 : 0;
+  p.gx = h->gx; p.gy = h->gy; p.LW = h->LW; p.LH = h->LH;
+  p.scatter = reinterpret_cast<const uint16_t*>(scatter); p.aux = h->aux; p.obs_full = h->obs_full;
   int nw; unsigned grid; size_t lds;
   DeviceGuard g(h->device);
   if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
@@ -908,7 +925,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     HIP_TRY(hipGetLastError());
     return MG_OK;
   }
-  if (objdrop || reset_gen) return fail(MG_EINVAL, "objdrop / gen injection needs a mutable-grid handle");
+  if (objdrop || reset_gen || scatter) return fail(MG_EINVAL, "objdrop / gen / scatter injection needs a mutable-grid handle");
   launch_geometry(h, h->use_table, &nw, &grid, &lds);
   const int fast = (op == OP_STEP && !order && !respawn && !reset_spawn && !random_actions && !h->buf.env_reward) ? 1 : 0;
   hipLaunchKernelGGL(h->use_table ? h->var->table[fast] : h->var->generic[fast], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
@@ -923,9 +940,14 @@ int enable_dynamic(mg_handle* h, const std::vector<uint8_t>& kinds, int gx, int 
   if (!h->dvar) return fail(MG_EUNSUPPORTED, "no mutable-grid kernel instantiated for this (n_agents, view_size)");
   DeviceGuard g(h->device);
   if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
-  int nw; unsigned grid; size_t lds;
-  dyn_geometry(h, &nw, &grid, &lds);
-  if (lds > (size_t)kLdsLimit) return fail(MG_EUNSUPPORTED, "grid too large for the mutable-grid kernel's LDS budget");
+  {
+    const int lw0 = h->LW, lh0 = h->LH;
+    h->LW = std::max(c.width, gx + 1); h->LH = std::max(c.height, gy + 1);
+    int nw; unsigned grid; size_t lds;
+    dyn_geometry(h, &nw, &grid, &lds);
+    h->LW = lw0; h->LH = lh0;
+    if (lds > (size_t)kLdsLimit) return fail(MG_EUNSUPPORTED, "grid too large for the mutable-grid kernel's LDS budget");
+  }
   int rc = MG_OK;
   if (!h->grid) {
     if (rc == MG_OK) rc = dalloc(h, &h->base_grid, (size_t)h->GW);
@@ -935,16 +957,17 @@ int enable_dynamic(mg_handle* h, const std::vector<uint8_t>& kinds, int gx, int 
   }
   std::vector<uint32_t> base((size_t)h->GW, 0u);
   for (size_t i = 0; i < kinds.size(); ++i) base[i >> 2] |= (uint32_t)kinds[i] << (8 * (i & 3));
-  std::vector<double> d((size_t)c.width * c.height);
-  for (int y = 0; y < c.height; ++y)
-    for (int x = 0; x < c.width; ++x) {
-      const long dx = x - gx, dy = y - gy;
-      d[(size_t)y * c.width + x] = sqrt((double)(dx * dx + dy * dy));   // np.linalg.norm (v8:192)
-    }
+  // relative distance LUT: d[|dy|*LW + |dx|] = np.linalg.norm((dx, dy)) (v8:192).  (gx, gy) can lie outside a
+  // small grid (the (13,13) fallback of get_goal_position, v8:167), so the table covers max(W, gx+1) x max(H, gy+1).
+  const int LW = std::max(c.width, gx + 1), LH = std::max(c.height, gy + 1);
+  if ((size_t)LW * LH > (size_t)64 * 64) return fail(MG_EINVAL, "goal too far outside the grid");
+  std::vector<double> d((size_t)LW * LH);
+  for (int dy = 0; dy < LH; ++dy)
+    for (int dx = 0; dx < LW; ++dx) d[(size_t)dy * LW + dx] = sqrt((double)((long)dx * dx + (long)dy * dy));
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(h->base_grid, base.data(), base.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->dist_lut, d.data(), d.size() * 8, hipMemcpyHostToDevice));
-  h->gx = gx; h->gy = gy;
+  h->gx = gx; h->gy = gy; h->LW = LW; h->LH = LH;
   h->dynamic = true; h->use_table = false; h->n_entries = 0;
   h->have_map = true;
   h->buf.carry = h->carry; h->buf.grid = h->grid; h->buf.grid_words = h->GW; h->buf.mutable_grid = 1;
@@ -969,7 +992,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (c.kernel_path < MG_PATH_AUTO || c.kernel_path > MG_PATH_TABLE) return fail(MG_EINVAL, "unknown kernel_path");
   if (c.env_id_base < 0 || (uint64_t)c.env_id_base + (uint64_t)c.n_envs > 0xFFFFFFFFull)
     return fail(MG_EINVAL, "global env ids must fit 32 bits");
-  if (c.env_kind != MG_KIND_STATIC && c.env_kind != MG_KIND_DOORKEY) return fail(MG_EINVAL, "unknown env_kind");
+  if (c.env_kind < MG_KIND_STATIC || c.env_kind > MG_KIND_MEETUP) return fail(MG_EINVAL, "unknown env_kind");
   const Variant* var = nullptr;
   for (const Variant& v : kVariants)
     if (v.A == c.n_agents && v.V == c.view_size) var = &v;
@@ -981,8 +1004,18 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
     if (c.kernel_path == MG_PATH_TABLE && !var->table[0]) return fail(MG_EUNSUPPORTED, "no table kernel for this view_size");
   } else {
     if (!dvar) return fail(MG_EUNSUPPORTED, "no mutable-grid kernel instantiated for this (n_agents, view_size)");
-    if (c.width != c.height || c.width < 5) return fail(MG_EINVAL, "DoorKey needs a square grid of size >= 5");
     if (c.kernel_path == MG_PATH_TABLE) return fail(MG_EUNSUPPORTED, "no table kernel for mutable grids");
+    if (c.env_kind == MG_KIND_DOORKEY) {
+      if (c.width != c.height || c.width < 5) return fail(MG_EINVAL, "DoorKey needs a square grid of size >= 5");
+    } else {
+      const int interior = (c.width - 2) * (c.height - 2);
+      if (c.gen_n_clutter < 0 || c.gen_n_goals < 0 || c.gen_n_goals + c.gen_n_clutter > MG_MAX_SCATTER)
+        return fail(MG_EINVAL, "gen_n_goals + gen_n_clutter must be in [0, 64]");
+      if (c.env_kind == MG_KIND_CLUTTERED && c.gen_n_goals > 1) return fail(MG_EINVAL, "Cluttered has one goal: gen_n_goals is 0 or 1");
+      if (c.env_kind == MG_KIND_MEETUP && (c.gen_n_goals < 1 || c.gen_n_goals > 3))
+        return fail(MG_EUNSUPPORTED, "Meetup supports 1 to 3 goals");
+      if (c.gen_n_goals + c.gen_n_clutter + 1 + c.n_agents > interior) return fail(MG_EINVAL, "more objects than interior cells");
+    }
     var = nullptr;
   }
 
@@ -995,7 +1028,8 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   mg_handle* h = new mg_handle();
   h->cfg = c; h->device = device; h->var = var; h->t = 0; h->have_map = h->have_reset = false;
   h->dynamic = false; h->dvar = dvar; h->GW = (c.width * c.height + 3) / 4;
-  h->base_grid = nullptr; h->carry = nullptr; h->grid = nullptr;
+  h->base_grid = nullptr; h->carry = nullptr; h->grid = nullptr; h->aux = nullptr; h->obs_full = nullptr;
+  h->full_obs = c.env_kind == MG_KIND_MEETUP; h->LW = c.width; h->LH = c.height;
   h->use_table = false; h->n_entries = 0; h->view_table = nullptr; h->cell_index = nullptr;
   h->stride = (c.n_envs + 63) / 64 * 64;
   h->n_chunks = h->stride / 64;
@@ -1021,11 +1055,13 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   memset(&h->buf, 0, sizeof(h->buf));
   int rc = MG_OK;
   if (rc == MG_OK) rc = dalloc(h, &h->map_pad, (size_t)h->PW * h->PH);
-  if (rc == MG_OK) rc = dalloc(h, &h->dist_lut, (size_t)c.width * c.height);
+  if (rc == MG_OK) rc = dalloc(h, &h->dist_lut, (size_t)64 * 64);
   if (rc == MG_OK) rc = dalloc(h, &h->cell_index, (size_t)c.width * c.height);
   if (rc == MG_OK && var) rc = dalloc(h, &h->view_table, (size_t)c.width * c.height * 4 * (var->entw ? var->entw : 4));
   if (rc == MG_OK) rc = dalloc(h, &h->err, 1);
-  if (rc == MG_OK) rc = dalloc(h, &h->buf.obs_image, A * S * rowb);
+  if (rc == MG_OK && !h->full_obs) rc = dalloc(h, &h->buf.obs_image, A * S * rowb);
+  if (rc == MG_OK && h->full_obs) rc = dalloc(h, &h->obs_full, S * (size_t)c.width * c.height * 3);
+  if (rc == MG_OK && (c.env_kind == MG_KIND_MEETUP || c.env_kind == MG_KIND_CLUTTERED)) rc = dalloc(h, &h->aux, S * 4);
   if (rc == MG_OK) rc = dalloc(h, &h->buf.reward, A * S);
   if (rc == MG_OK && c.emit_env_reward) rc = dalloc(h, &h->buf.env_reward, A * S);
   if (rc == MG_OK) rc = dalloc(h, &h->buf.dir_done, S * (size_t)h->dd_bytes);
@@ -1038,15 +1074,22 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   }
   h->buf.n_envs = c.n_envs; h->buf.env_stride = h->stride; h->buf.n_agents = c.n_agents; h->buf.obs_cell_bytes = rowb;
   h->buf.dir_done_bytes = h->dd_bytes;
-  if (c.env_kind == MG_KIND_DOORKEY) {
-    // the part of DoorKeyEnv._gen_grid that is the same for every env and every reset
-    // (doorkey.py:38-44): border walls and the goal at (W-2, H-2); the rest is drawn on device
+  h->buf.aux = h->aux; h->buf.obs_full = h->obs_full;
+  h->buf.obs_full_bytes = h->full_obs ? c.width * c.height * 3 : 0;
+  if (c.env_kind != MG_KIND_STATIC) {
+    // the part of _gen_grid that is the same for every env and every reset: border walls (wall_rect) and,
+    // for DoorKey (doorkey.py:38-44) and Cluttered without randomize_goal (cluttered.py:31), the goal at
+    // (W-2, H-2); the rest is drawn on device
     std::vector<uint8_t> kinds((size_t)c.width * c.height, 0);
     for (int y = 0; y < c.height; ++y)
       for (int x = 0; x < c.width; ++x)
         if (x == 0 || y == 0 || x == c.width - 1 || y == c.height - 1) kinds[(size_t)y * c.width + x] = (uint8_t)K_WALL;
-    kinds[(size_t)(c.height - 2) * c.width + (c.width - 2)] = (uint8_t)K_GOAL;
-    rc = enable_dynamic(h, kinds, c.width - 2, c.height - 2);
+    const bool fixed_goal = c.env_kind == MG_KIND_DOORKEY || (c.env_kind == MG_KIND_CLUTTERED && c.gen_n_goals == 0);
+    if (fixed_goal) kinds[(size_t)(c.height - 2) * c.width + (c.width - 2)] = (uint8_t)K_GOAL;
+    // shaper goal (v8:159-169): that cell; Meetup has no goal cell -> the (13,13) fallback; a scattered Cluttered
+    // goal is per env (mg_buffers.aux word 0) and overrides this in the kernel
+    const bool no_goal = c.env_kind == MG_KIND_MEETUP;
+    rc = enable_dynamic(h, kinds, no_goal ? 13 : c.width - 2, no_goal ? 13 : c.height - 2);
     if (rc != MG_OK) { mg_destroy(h); return rc; }
   }
   *out = h;
@@ -1218,6 +1261,15 @@ int mg_step_replay_dyn(mg_handle* h, const void* actions, const uint8_t* order, 
   if (!h->have_reset) return fail(MG_ESTATE, "mg_reset must be called before mg_step_replay_dyn");
   int rc = launch(h, OP_STEP, actions, order, respawn, reset_spawn, nullptr, 0, nullptr, objdrop, reset_gen);
   if (rc == MG_OK) h->t += 1;
+  return rc;
+}
+
+int mg_reset_inject_scatter(mg_handle* h, const uint8_t* env_mask, const int8_t* spawn, const int8_t* scatter) {
+  if (!h) return fail(MG_EINVAL, "null handle");
+  if (h->cfg.env_kind != MG_KIND_CLUTTERED && h->cfg.env_kind != MG_KIND_MEETUP)
+    return fail(MG_EINVAL, "scatter injection is for the CLUTTERED / MEETUP kinds");
+  int rc = launch(h, OP_RESET, nullptr, nullptr, nullptr, spawn, env_mask, 0, nullptr, nullptr, nullptr, scatter);
+  if (rc == MG_OK) h->have_reset = true;
   return rc;
 }
 

@@ -9,7 +9,9 @@ MG_OK = 0
 SHAPING_NONE, SHAPING_V8 = 0, 1
 PATH_AUTO, PATH_GENERIC, PATH_TABLE = 0, 1, 2
 ERR_BAD_ACTION, ERR_BAD_RESPAWN, ERR_BAD_ORDER, ERR_MISSING_DRAW = 1, 2, 4, 8
-KIND_STATIC, KIND_DOORKEY = 0, 1
+KIND_STATIC, KIND_DOORKEY, KIND_CLUTTERED, KIND_MEETUP = 0, 1, 2, 3
+KINDS = {'static': KIND_STATIC, 'doorkey': KIND_DOORKEY, 'cluttered': KIND_CLUTTERED, 'meetup': KIND_MEETUP}
+GEN_LAVA = 1
 
 
 def kind_id(type_, color=0, state=0):
@@ -28,6 +30,7 @@ class MgConfig(C.Structure):
       ('shaping_kind', C.c_int32), ('auto_reset', C.c_int32), ('env_kind', C.c_int32),
       ('emit_env_reward', C.c_int32), ('kernel_path', C.c_int32),
       ('n_envs', C.c_int64), ('env_id_base', C.c_int64), ('seed', C.c_uint64),
+      ('gen_n_goals', C.c_int32), ('gen_n_clutter', C.c_int32), ('gen_flags', C.c_int32), ('reserved1', C.c_int32),
   ]
 
 
@@ -37,6 +40,7 @@ class MgBuffers(C.Structure):
       ('obs_image', C.c_void_p), ('reward', C.c_void_p), ('env_reward', C.c_void_p), ('dir_done', C.c_void_p),
       ('dir_done_bytes', C.c_int32), ('reserved', C.c_int32), ('env_state', C.c_void_p),
       ('carry', C.c_void_p), ('grid', C.c_void_p), ('grid_words', C.c_int32), ('mutable_grid', C.c_int32),
+      ('aux', C.c_void_p), ('obs_full', C.c_void_p), ('obs_full_bytes', C.c_int32), ('reserved2', C.c_int32),
   ]
 
 
@@ -51,6 +55,7 @@ SYMBOLS = {
     'mg_step_replay': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mg_reset_inject_dyn': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mg_step_replay_dyn': (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
+    'mg_reset_inject_scatter': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mg_export_grid': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_step_random': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_get_buffers': (C.c_int, [C.c_void_p, C.POINTER(MgBuffers)]),

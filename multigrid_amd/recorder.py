@@ -20,17 +20,19 @@ generate_trajectory_video.py:180-241).  Purpose: make bit-exact parity reproduci
   recorded episode) and compares every recorded output; used by tests and by the CLI.
 
 Fixture schema (E episodes, T = longest episode, A agents, V view size):
-  meta          json: schema, kind ('static' | 'doorkey'), width, height, n_agents, view_size,
+  meta          json: schema, kind ('static' | 'doorkey' | 'cluttered' | 'meetup'), width, height, n_agents, view_size,
                 max_steps, see_through_walls, competitive, shaping ('none' | 'v8'), source
   cells         uint8[H, W, 3]            layout (kind 'static'), encode() triples
   length        int32[E]                  steps recorded for the episode (it ended with done, or at T)
   spawn         int8[E, A, 4]             (x, y, dir, 0) accepted at reset
   gen           int8[E, 4]                DoorKey (split_idx, door_idx, key_x, key_y)
+  scatter       int8[E, n_obj, 2]         cluttered / meetup: accepted (x, y) of every scattered object in draw order
+                                          (meta then also holds n_goals, n_clutter, walls_are_lava)
   actions       uint8[E, T, A]
   order         uint8[E, T, A]            order[e, t, k] = agent acting k-th
   respawn       int8[E, T, A, 4]          (x, y, dir, 0) if agent a finished in that step, x = -1 otherwise
   objdrop       int8[E, T, A, 4]          (x, y, 0, 0) where the object it carried was re-placed, x = -1 otherwise
-  obs_image     uint8[E, T+1, A, V, V, 3] index 0 = the reset observation
+  obs_image     uint8[E, T+1, A, V, V, 3] index 0 = the reset observation (fully observed kinds: [E, T+1, A, W, H, 3])
   obs_dir       uint8[E, T+1, A]
   env_reward    float64[E, T, A]
   shaped_reward float64[E, T, A]          only when a shaper was attached
@@ -114,7 +116,10 @@ class Recorder:
     spawn = np.zeros((A, 4), np.int8)
     for a, x, y, d in self._agents[-A:]:
       spawn[a] = (x, y, d, 0)
-    out = dict(spawn=spawn, gen=self._gen(), actions=[], order=[], respawn=[], objdrop=[], env_reward=[], shaped_reward=[],
+    scatter = np.array([[x, y] for (_, x, y) in self._objects], np.int8).reshape(-1, 2)
+    if self.kind not in ('cluttered', 'meetup'):
+      scatter = np.zeros((0, 2), np.int8)
+    out = dict(spawn=spawn, gen=self._gen(), scatter=scatter, actions=[], order=[], respawn=[], objdrop=[], env_reward=[], shaped_reward=[],
                done=[], obs_image=[np.stack(obs['image'])], obs_dir=[np.array(obs['direction'], np.uint8)])
     pos, d, carry = self._state()
     out.update(agent_pos=[pos], agent_dir=[d], carry=[carry])
@@ -164,7 +169,7 @@ def stack_episodes(episodes, meta, cells=None):
     arrs = []
     for ep in episodes:
       v = ep[k]
-      if k in ('spawn', 'gen'):
+      if k in ('spawn', 'gen', 'scatter'):
         arrs.append(v)
         continue
       full = T + 1 if k in ('obs_image', 'obs_dir', 'agent_pos', 'agent_dir', 'carry') else T
@@ -199,6 +204,7 @@ def load(path):
     rec['length'] = np.full(E, T, np.int32)
   E, T, A = rec['actions'].shape
   rec.setdefault('gen', np.zeros((E, 4), np.int8))
+  rec.setdefault('scatter', np.zeros((E, 0, 2), np.int8))
   if 'objdrop' not in rec:
     rec['objdrop'] = np.full((E, T, A, 4), -1, np.int8)
     rec['objdrop'][..., 2:] = 0
@@ -216,8 +222,12 @@ def replay_on_device(rec, device=0, check_state=True):
   kw = dict(n_envs=E, n_agents=A, view_size=m['view_size'], max_steps=m['max_steps'],
             see_through_walls=bool(m.get('see_through_walls', False)), competitive=bool(m.get('competitive', False)),
             shaping='v8' if shaped else None, auto_reset=False, device=device, emit_env_reward=True)
+  full = m['kind'] == 'meetup'
   if m['kind'] == 'doorkey':
     env = BatchedMultiGrid(None, kind='doorkey', size=m['width'], **kw)
+  elif m['kind'] in ('cluttered', 'meetup'):
+    env = BatchedMultiGrid(None, kind=m['kind'], size=m['width'], n_goals=m['n_goals'], n_clutter=m['n_clutter'],
+                           walls_are_lava=bool(m.get('walls_are_lava', False)), **kw)
   else:
     env = BatchedMultiGrid(rec['cells'], **kw)
   dev = env.device
@@ -229,13 +239,20 @@ def replay_on_device(rec, device=0, check_state=True):
     if n:
       bad[name] = bad.get(name, 0) + n
 
+  def images():
+    if full:       # one whole-grid image per env on the device, A identical copies in the fixture
+      return np.repeat(env.obs_full.cpu().numpy()[:, None], A, axis=1)
+    return env.obs_image.cpu().numpy().transpose(1, 0, 2, 3, 4)
+
   try:
-    if env.mutable_grid:
+    if m['kind'] in ('cluttered', 'meetup'):
+      env.reset(spawn=am(rec['spawn']), scatter=rec['scatter'])
+    elif env.mutable_grid:
       env.reset(spawn=am(rec['spawn']), gen=torch.from_numpy(rec['gen']).to(dev) if m['kind'] == 'doorkey' else None)
     else:
       env.reset(spawn=am(rec['spawn']))
     live = rec['length'] >= 0
-    cmp('obs_image[0]', env.obs_image.cpu().numpy().transpose(1, 0, 2, 3, 4), rec['obs_image'][:, 0], live)
+    cmp('obs_image[0]', images(), rec['obs_image'][:, 0], live)
     cmp('obs_dir[0]', env.obs_dir.cpu().numpy().T, rec['obs_dir'][:, 0], live)
     steps = 0
     for t in range(T):
@@ -249,7 +266,7 @@ def replay_on_device(rec, device=0, check_state=True):
       extra = dict(objdrop=am(rec['objdrop'][:, t])) if env.mutable_grid else {}
       env.step_replay(am(act), am(order), am(rec['respawn'][:, t]), **extra)
       steps += int(live.sum())
-      cmp('obs_image', env.obs_image.cpu().numpy().transpose(1, 0, 2, 3, 4), rec['obs_image'][:, t + 1], live)
+      cmp('obs_image', images(), rec['obs_image'][:, t + 1], live)
       cmp('obs_dir', env.obs_dir.cpu().numpy().T, rec['obs_dir'][:, t + 1], live)
       cmp('env_reward', env.env_reward.cpu().numpy().T.view(np.int64), rec['env_reward'][:, t].view(np.int64), live)
       if shaped:

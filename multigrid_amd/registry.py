@@ -39,6 +39,26 @@ for _id, _size, _agents in (('MultiGrid-DoorKey-6x6-v0', 6, 2), ('MultiGrid-Door
   register(_id, dict(kind='doorkey', size=_size, n_agents=_agents, view_size=7, max_steps=10 * _size * _size,
                      see_through_walls=False, competitive=False))
 
+# ClutteredMultiGrid with a fresh layout per reset (multigrid_envs/cluttered.py:13-45, 187-199, 290-324).
+# The *-Minigrid-* ids differ only in minigrid_mode (container shapes, multigrid.py:983,1053) and are not listed.
+for _id, _size, _agents, _clutter, _steps in (('MultiGrid-Cluttered-v0', 15, 3, 25, 250),
+                                             ('MultiGrid-Cluttered-Single-v0', 15, 1, 25, 250),
+                                             ('MultiGrid-Cluttered-Single-6x6-v0', 6, 1, 5, 50)):
+  register(_id, dict(kind='cluttered', size=_size, n_agents=_agents, view_size=5, max_steps=_steps, n_goals=1,
+                     n_clutter=_clutter, see_through_walls=False, competitive=False))
+
+# MeetupEnv family (multigrid_envs/meetup.py:26-236): fully observed, view size unused (default 7), max_steps 250.
+# MultiGrid-Meetup-Multi-12x12-v0 (5 goals) is not registered: the kernel keeps at most three goal doors.
+for _id, _size, _agents, _goals, _clutter in (('MultiGrid-Meetup-v0', 15, 3, 3, 0), ('MultiGrid-Meetup-Empty-6x6-v0', 6, 3, 3, 0),
+                                             ('MultiGrid-Meetup-Single-6x6-v0', 6, 3, 1, 0),
+                                             ('MultiGrid-Meetup-Random-8x8-v0', 8, 3, 3, 5), ('MultiGrid-Meetup-Single-8x8-v0', 8, 3, 1, 5),
+                                             ('MultiGrid-Meetup-Random-10x10-v0', 10, 3, 3, 10),
+                                             ('MultiGrid-Meetup-Empty-12x12-v0', 12, 3, 3, 0), ('MultiGrid-Meetup-Empty-15x15-v0', 15, 3, 3, 0),
+                                             ('MultiGrid-Meetup-Random-12x12-v0', 12, 3, 3, 10),
+                                             ('MultiGrid-Meetup-Single-12x12-v0', 12, 3, 1, 0)):
+  register(_id, dict(kind='meetup', size=_size, n_agents=_agents, view_size=7, max_steps=250, n_goals=_goals,
+                     n_clutter=_clutter, see_through_walls=False, competitive=False))
+
 
 def make_batched(env_id, n_envs, **kw):
   """N device-resident envs of `env_id` (BatchedMultiGrid)."""

@@ -756,7 +756,7 @@ uint32_t mgo_step_state(const mgo_env* e) {
   uint32_t d = 0;
   for (int a = 0; a < e->A; ++a) d |= (uint32_t)(e->done[a] != 0) << a;
   uint32_t w = (uint32_t)e->step_count | (d << 16);
-  if (e->kind != KIND_STATIC) w |= (uint32_t)e->spawn_w << 24;   /* dynamic-grid kinds keep the spawn region here */
+  if (e->kind == KIND_DOORKEY) w |= (uint32_t)e->spawn_w << 24;  /* DoorKey keeps the spawn region (split_idx) here */
   return w;
 }
 /* One-byte cell kind used by the product's per-env grids: 0 = None, door = 128 + color*4 + state,
@@ -791,6 +791,11 @@ void mgo_aux_words(const mgo_env* e, uint32_t* out /* [4] */) {
   if (e->kind == KIND_MEETUP) {
     for (int i = 0; i < e->n_goals; ++i) out[i] = (uint32_t)e->goal_x[i] | ((uint32_t)e->goal_y[i] << 6);
     for (int a = 0; a < e->A && a < 4; ++a) out[3] |= (uint32_t)e->past_dist[a] << (8 * a);
+  }
+  if (e->kind == KIND_CLUTTERED && e->n_goals) {        /* the scattered goal, which the v8 shaper measures to */
+    int gx, gy;
+    goal_position(e, &gx, &gy);
+    out[0] = (uint32_t)gx | ((uint32_t)gy << 6);
   }
 }
 /* what the last step/reset drew: order[A], respawn[A][4], spawn[A][4] */

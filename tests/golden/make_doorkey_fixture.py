@@ -1,4 +1,4 @@
-"""Records tests/golden/replay_doorkey_6x6.npz and replay_playground_9x9.npz with multigrid_amd.recorder
+"""Records tests/golden/replay_doorkey_6x6.npz, replay_playground_9x9.npz and replay_meetup_8x8.npz with multigrid_amd.recorder
 from the pure-Python object-style restatement (oracle/py_ref_env.py), driven the way the reference
 drives its env (env-local PCG64 for placement, global np.random.shuffle for the agent order).
 
@@ -120,6 +120,18 @@ def main():
   recorder.save(os.path.join(here, 'replay_playground_9x9.npz'), rec)
   print('playground', 'goal touches', int((rec['env_reward'] > 0).sum()), 'objdrops', int((rec['objdrop'][..., 0] >= 0).sum()),
         'respawns', int((rec['respawn'][..., 0] >= 0).sum()))
+
+  env = py_ref_env.PyMeetupEnv(size=8, n_agents=3, n_goals=3, n_clutter=5, max_steps=60, seed=31, order_fn=global_shuffle_order(3))
+  np.random.seed(5)
+  rng = np.random.RandomState(6)
+  r = recorder.Recorder(env, kind='meetup')
+  eps = [r.episode(lambda e, obs, t: rng.choice(7, size=3, p=[.15, .15, .5, .05, .05, .05, .05]), 60) for _ in range(16)]
+  meta = dict(kind='meetup', width=8, height=8, n_agents=3, view_size=7, max_steps=60, see_through_walls=False,
+              competitive=False, shaping='none', n_goals=3, n_clutter=5, walls_are_lava=False,
+              source='oracle/py_ref_env.py restatement (not cxh42 code)')
+  rec = recorder.stack_episodes(eps, meta)
+  recorder.save(os.path.join(here, 'replay_meetup_8x8.npz'), rec)
+  print('meetup', 'lengths', rec['length'].tolist(), 'nonzero rewards', int((rec['env_reward'] != 0).sum()))
 
 
 if __name__ == '__main__':

@@ -14,7 +14,7 @@ from multigrid_amd import recorder
 from oracle import c_oracle, py_ref_env
 
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
-FIXTURES = ['replay_cluttered_fixed_15x15.npz', 'replay_doorkey_6x6.npz', 'replay_playground_9x9.npz']
+FIXTURES = ['replay_cluttered_fixed_15x15.npz', 'replay_doorkey_6x6.npz', 'replay_playground_9x9.npz', 'replay_meetup_8x8.npz']
 
 
 def replay_on_oracle(rec):
@@ -25,8 +25,12 @@ def replay_on_oracle(rec):
   bad = 0
   for e in range(E):
     env = c_oracle.OracleEnv(rec.get('cells') if m['kind'] == 'static' else None, W=m['width'], H=m['height'], A=A,
-                             V=m['view_size'], max_steps=m['max_steps'], shaping=int(shaped), kind=m['kind'])
-    obs = env.reset(spawn=rec['spawn'][e, :, :3], gen=rec['gen'][e] if m['kind'] == 'doorkey' else None)
+                             V=m['view_size'], max_steps=m['max_steps'], shaping=int(shaped), kind=m['kind'],
+                             n_goals=m.get('n_goals', 0), n_clutter=m.get('n_clutter', 0), lava=m.get('walls_are_lava', False))
+    if m['kind'] in ('cluttered', 'meetup'):
+      obs = env.reset(spawn=rec['spawn'][e, :, :3], scatter=rec['scatter'][e])
+    else:
+      obs = env.reset(spawn=rec['spawn'][e, :, :3], gen=rec['gen'][e] if m['kind'] == 'doorkey' else None)
     bad += int((np.stack(obs['image']) != rec['obs_image'][e, 0]).sum())
     for t in range(int(rec['length'][e])):
       obs, rew, done, _ = env.step(rec['actions'][e, t], order=rec['order'][e, t], respawn=rec['respawn'][e, t, :, :3],
@@ -48,7 +52,7 @@ def replay_on_oracle(rec):
 @pytest.mark.parametrize('name', FIXTURES)
 def test_fixture_replays_on_the_c_oracle(name):
   rec = recorder.load(os.path.join(GOLDEN, name))
-  assert rec['meta']['kind'] in ('static', 'doorkey')
+  assert rec['meta']['kind'] in ('static', 'doorkey', 'cluttered', 'meetup')
   assert replay_on_oracle(rec) == 0
 
 
