@@ -43,12 +43,20 @@ int main(int argc, char** argv) {
   if (!f || fread(cells.data(), 1, cells.size(), f) != cells.size()) { fprintf(stderr, "bad map\n"); return 2; }
   fclose(f);
   const int R = 16;
-  int dk_size = 0, dk_agents = 0;
-  if (const char* w = getenv("MG_WORKLOAD")) sscanf(w, "doorkey%dx%d", &dk_size, &dk_agents);
-  const int A = dk_size ? dk_agents : 3, V = dk_size ? 7 : 5;
-  // bytes one env-step has to move: obs + dir_done + rewards + actions + env_state r/w (+ carry and grid r/w)
-  const double env_bytes = A * V * V * 3 + (A < 4 ? 4 : 8) + 8.0 * A + 4 + 8.0 * (A + 1) +
-                           (dk_size ? 8 + 2.0 * ((dk_size * dk_size + 3) / 4 * 4) : 0);
+  // workload: "" = Cluttered-Fixed-15x15 (shared map); doorkey<S>x<A>, meetup<S>x<A> (3 goals, no clutter),
+  // cluttered<S>x<A> (random goal + 25 walls per env and reset) = mutable-grid kernel
+  int dk_size = 0, dk_agents = 0, kind = MG_KIND_STATIC;
+  if (const char* w = getenv("MG_WORKLOAD")) {
+    if (sscanf(w, "doorkey%dx%d", &dk_size, &dk_agents) == 2) kind = MG_KIND_DOORKEY;
+    else if (sscanf(w, "meetup%dx%d", &dk_size, &dk_agents) == 2) kind = MG_KIND_MEETUP;
+    else if (sscanf(w, "cluttered%dx%d", &dk_size, &dk_agents) == 2) kind = MG_KIND_CLUTTERED;
+  }
+  const int A = dk_size ? dk_agents : 3, V = kind == MG_KIND_DOORKEY ? 7 : 5;
+  // bytes one env-step has to move: obs + dir_done + rewards + actions + env_state r/w (+ carry, aux and grid r/w)
+  const double obs_bytes = kind == MG_KIND_MEETUP ? dk_size * dk_size * 3 : A * V * V * 3;
+  const double env_bytes = obs_bytes + (A < 4 ? 4 : 8) + 8.0 * A + 4 + 8.0 * (A + 1) +
+                           (dk_size ? 8 + 2.0 * ((dk_size * dk_size + 3) / 4 * 4) : 0) +
+                           ((kind == MG_KIND_MEETUP || kind == MG_KIND_CLUTTERED) ? 32 : 0);
   std::vector<Api> apis;
   for (int i = 5; i < argc; ++i) {
     Api a{};
@@ -62,8 +70,10 @@ int main(int argc, char** argv) {
     c.auto_reset = 1; c.n_envs = n; c.seed = 0xC0FFEE;
     c.kernel_path = getenv("MG_PATH") ? atoi(getenv("MG_PATH")) : 0;
     if (dk_size) {
-      c.width = c.height = dk_size; c.n_agents = dk_agents; c.view_size = 7; c.max_steps = 10 * dk_size * dk_size;
-      c.env_kind = MG_KIND_DOORKEY;
+      c.width = c.height = dk_size; c.n_agents = dk_agents; c.view_size = V; c.env_kind = kind;
+      c.max_steps = kind == MG_KIND_DOORKEY ? 10 * dk_size * dk_size : 250;
+      if (kind == MG_KIND_MEETUP) { c.gen_n_goals = 3; c.gen_n_clutter = 0; c.view_size = 7; }
+      if (kind == MG_KIND_CLUTTERED) { c.gen_n_goals = 1; c.gen_n_clutter = 25; }
     }
     if (a.create(&c, 0, &a.h) != MG_OK) { fprintf(stderr, "create: %s\n", a.last_error()); return 1; }
     if (!dk_size && a.set_map(a.h, cells.data()) != MG_OK) { fprintf(stderr, "map: %s\n", a.last_error()); return 1; }
