@@ -28,12 +28,17 @@ constexpr uint32_t K_DOOR_YELLOW_LOCKED = 128 + 4 * 4 + 2;     // Door('yellow',
 constexpr uint32_t K_KEY_YELLOW = MG_T_KEY * 8 + 4;            // Key('yellow'), doorkey.py:65
 constexpr uint32_t K_DOOR_RED_LOCKED = 128 + 0 * 4 + 2;        // Door(color='red', is_locked=True), meetup.py:69
 constexpr uint32_t K_LAVA = MG_T_LAVA * 8 + 0;                 // red lava
+constexpr uint32_t K_AGENT0 = 224;                             // 224 + 4*agent + dir: LDS only, never stored to HBM
 enum { P_GEN = 4, P_KEY = 5, P_OBJDROP = 6 };
 
 // kind id -> encode() triple (type | color<<8 | state<<16) + behaviour flags.  256 entries, built
 // once per workgroup into LDS.
 __host__ __device__ inline uint32_t kind_word(uint32_t k) {
   if (k == 0u) return (uint32_t)MG_T_EMPTY | F_FREE;
+  if (k >= K_AGENT0) {   // an agent marked into the LDS grid while a fully observed image is encoded (emit_full)
+    const uint32_t id = ((k - K_AGENT0) >> 2) & 3u, dir = k & 3u;
+    return (uint32_t)MG_T_AGENT | (id << 8) | (dir << 16);        // Agent.encode, multigrid.py:137-139
+  }
   if (k >= 128u) {
     const uint32_t color = ((k - 128u) >> 2) & 7u, state = k & 3u;
     uint32_t w = (uint32_t)MG_T_DOOR | (color << 8) | (state << 16) | F_DOOR;
@@ -214,32 +219,62 @@ __device__ __forceinline__ uint32_t meetup_dist(const Params& p, uint64_t pd, co
 }
 
 // Fully observed obs (multigrid.py:1043-1045): Grid.encode() of the whole grid, [x][y][3] bytes, with
-// the agents in their cells as (10, id, dir).  Each lane writes its env's image into the wave's
-// staging area byte by byte; the 64 images then leave as one contiguous run of 16-byte vectors.
+// the agents in their cells as (10, id, dir).  No staging: the wave's grids already sit in LDS
+// cell-major, so the wave gathers the 64 images straight into output order — lane l produces the
+// 16-byte vectors l, l+64, ... of the chunk's 64*W*H*3 contiguous bytes and every store instruction
+// writes 1 KB of contiguous bytes.  The agents are marked into the LDS grid for the duration (kinds
+// K_AGENT0 + 4*id + dir); the next chunk's copy-in overwrites every interior cell, so they never leak.
 template <int A>
-__device__ __forceinline__ void emit_full(const Params& p, const uint8_t* g, const uint32_t* lut, uint64_t pd,
-                                          uint32_t* stage, int lane, uint8_t* gchunk) {
-  const int FB = p.W * p.H * 3;
-  uint8_t* sb = reinterpret_cast<uint8_t*>(stage) + lane * FB;
-  for (int x = 0; x < p.W; ++x)
-    for (int y = 0; y < p.H; ++y) {
-      const uint32_t w = lut[g_get(g, g_off(p, x, y))];
-      uint8_t* q = sb + (x * p.H + y) * 3;
-      q[0] = (uint8_t)w; q[1] = (uint8_t)(w >> 8); q[2] = (uint8_t)(w >> 16);
-    }
+__device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uint8_t* gwave, const uint32_t* lut,
+                                          const uint16_t* cpc, uint64_t pd, int lane, uint8_t* gchunk) {
+  const int cells = p.W * p.H, FB = cells * 3;
 #pragma unroll
   for (int b = 0; b < A; ++b) {
     const uint32_t o = pd_get(pd, b);
-    uint8_t* q = sb + (aw_x(o) * p.H + aw_y(o)) * 3;
-    q[0] = (uint8_t)MG_T_AGENT; q[1] = (uint8_t)b; q[2] = (uint8_t)aw_d(o);   // Agent.encode multigrid.py:137-139
+    g_set(g, g_off(p, aw_x(o), aw_y(o)), K_AGENT0 + 4u * (uint32_t)b + (uint32_t)aw_d(o));
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const int nv = 4 * FB;                        // 16-byte vectors in the 64-image chunk
-  const uint4* src = reinterpret_cast<const uint4*>(stage);
+  // lane l produces the 16-byte vectors l, l+64, ... of the chunk; 16 bytes starting at byte r0 of an
+  // image span exactly six consecutive cells (3*c0 + m .. 3*c0 + m + 15, m = r0 % 3), the last of
+  // which may belong to the next image
   uint4* dst = reinterpret_cast<uint4*>(gchunk);
-  for (int idx = lane; idx < nv; idx += kWave) dst[idx] = src[idx];
+  const int nv = 4 * FB;                        // 16-byte vectors in the 64-image chunk
+  int e = 0, r0 = 16 * lane;                    // image index within the chunk and byte offset within it
+  constexpr int UF = 2;                         // vectors per lane in flight (the dependent LDS reads of each overlap)
+  for (int q = lane; q < nv; q += UF * kWave) {
+    uint32_t k[UF][6], m[UF];
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+      while (r0 >= FB) { r0 -= FB; ++e; }
+      const bool live = q + u * kWave < nv;
+      const int c0 = live ? (int)__umulhi((uint32_t)r0, 0x55555556u) : 0;   // r0 / 3
+      m[u] = live ? (uint32_t)(r0 - 3 * c0) : 0u;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        int c = c0 + j, ee = live ? e : 0;
+        if (c >= cells) { c -= cells; ee += 1; }       // never past image 63: the chunk's last vector ends on its last byte
+        k[u][j] = gwave[(int)cpc[c] * kCellB + ee];
+      }
+      r0 += 16 * kWave;
+    }
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+      uint32_t w[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) w[j] = lut[k[u][j]] & 0xFFFFFFu;
+      // the six 3-byte codes as a byte stream, then 16 bytes from offset m
+      const uint32_t s0 = w[0] | (w[1] << 24), s1 = (w[1] >> 8) | (w[2] << 16), s2 = (w[2] >> 16) | (w[3] << 8);
+      const uint32_t s3 = w[4] | (w[5] << 24), s4 = w[5] >> 8;
+      uint4 v;
+      v.x = __builtin_amdgcn_alignbyte(s1, s0, m[u]);
+      v.y = __builtin_amdgcn_alignbyte(s2, s1, m[u]);
+      v.z = __builtin_amdgcn_alignbyte(s3, s2, m[u]);
+      v.w = __builtin_amdgcn_alignbyte(s4, s3, m[u]);
+      if (q + u * kWave < nv) dst[q + u * kWave] = v;
+    }
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -248,8 +283,8 @@ __device__ __forceinline__ void emit_full(const Params& p, const uint8_t* g, con
 // One chunk (64 envs) of one step()/reset() on mutable grids.
 template <int A, int V>
 __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, const uint32_t* lut, const uint32_t* base,
-                                          const uint16_t* pidx, uint32_t* stage, uint32_t* gw, int lane, int64_t env0,
-                                          const DynIn<A>& in, uint32_t& err_acc) {
+                                          const uint16_t* pidx, const uint16_t* cpc, uint32_t* stage, uint32_t* gw, int lane,
+                                          int64_t env0, const DynIn<A>& in, uint32_t& err_acc) {
   constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
   const int64_t n = env0 + lane;
   const bool active = n < p.n_envs;
@@ -268,9 +303,16 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       if (k < p.GW && ci < cells) gw[(int)pidx[ci] * kCellW + l4] = in.pre[k];
     }
   } else {
-    for (int k = 0; k < p.GW; ++k) {
-      const int ci = c4 + 4 * k;
-      if (ci < cells) gw[(int)pidx[ci] * kCellW + l4] = ghbm[k * kWave + lane];
+    // larger grids: rows fetched kPreMax at a time (all loads of a batch in flight together)
+    for (int k0 = 0; k0 < p.GW; k0 += kPreMax) {
+      uint32_t row[kPreMax];
+#pragma unroll
+      for (int j = 0; j < kPreMax; ++j) row[j] = (k0 + j < p.GW) ? ghbm[(k0 + j) * kWave + lane] : 0u;
+#pragma unroll
+      for (int j = 0; j < kPreMax; ++j) {
+        const int ci = c4 + 4 * (k0 + j);
+        if (k0 + j < p.GW && ci < cells) gw[(int)pidx[ci] * kCellW + l4] = row[j];
+      }
     }
   }
   // the rows above were written by other lanes than the ones that read them below
@@ -278,6 +320,8 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   uint8_t* const g = reinterpret_cast<uint8_t*>(gw) + lane;
+  bool dirty = false;            // this env's grid changed: the wave's rows go back to HBM only if some lane's did
+  auto gs = [&](int off, uint32_t k) { g_set(g, off, k); dirty = true; };
 
   uint64_t pd = 0;
   uint32_t shw[A];
@@ -340,7 +384,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
               // agent's old cell still counts as occupied (agent_pos is cleared only afterwards, :655)
               const bool inj = p.objdrop != nullptr;
               const uint32_t w = place_dyn<A>(p, g, pd, all, a, P_OBJDROP, p.W, inj, inj ? p.objdrop[n * A + a] : 0u, false, gid);
-              g_set(g, g_off(p, aw_x(w), aw_y(w)), ck);
+              gs(g_off(p, aw_x(w), aw_y(w)), ck);
               carry &= ~(255u << (8 * a));
               err |= w >> 16;
             }
@@ -351,29 +395,29 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
             err |= w >> 16;
           } else if (fl & (F_FREE | F_OVERLAP)) {                               // move_agent :834-847
             npd = fpos | ((uint32_t)d << 12);
-            if (fl & F_OVERLAP) g_set(g, ci, 0u);      // the Agent object replaces what was there, for good
+            if (fl & F_OVERLAP) gs(ci, 0u);      // the Agent object replaces what was there, for good
           }
         }
       } else if (act == 3u) {                                                   // _pickup :926-938
         if ((fl & F_PICKUP) && ck == 0u) {
           carry |= kf << (8 * a);
-          g_set(g, ci, 0u);
+          gs(ci, 0u);
         }
       } else if (act == 4u) {                                                   // _drop :940-951
         if ((fl & F_FREE) && !blocked && ck != 0u) {
-          g_set(g, ci, ck);
+          gs(ci, ck);
           carry &= ~(255u << (8 * a));
         }
       } else if (act == 5u) {                                                   // _toggle :953-961
         if (fl & F_DOOR) {                                                      // Door.toggle :112-122
           const uint32_t state = kf & 3u, color = ((kf - 128u) >> 2) & 7u;
           if (state == 2u) {
-            if (ck < 128u && (ck >> 3) == (uint32_t)MG_T_KEY && (ck & 7u) == color) g_set(g, ci, kf & ~3u);
+            if (ck < 128u && (ck >> 3) == (uint32_t)MG_T_KEY && (ck & 7u) == color) gs(ci, kf & ~3u);
           } else {
-            g_set(g, ci, kf ^ 1u);
+            gs(ci, kf ^ 1u);
           }
         } else if (fl & F_BOX) {
-          g_set(g, ci, 0u);                                                     // Box.toggle: replaced by its (empty) contents
+          gs(ci, 0u);                                                     // Box.toggle: replaced by its (empty) contents
         }
       }
       if (act > 6u) err |= MG_ERR_BAD_ACTION;                                   // assert False :902
@@ -422,7 +466,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   // ---- reset() (multigrid.py:466-501) / auto-reset: _gen_grid on this env's own grid ------------
   const bool do_reset = (!is_step) ? (p.mask ? (p.mask[active ? n : 0] != 0) : true) : (done_flag && p.auto_reset);
   if (do_reset) {
-    for (int ci = 0; ci < cells; ++ci) g_set(g, (int)pidx[ci] * kCellB, (base[ci >> 2] >> (8 * (ci & 3))) & 255u);
+    for (int ci = 0; ci < cells; ++ci) gs((int)pidx[ci] * kCellB, (base[ci >> 2] >> (8 * (ci & 3))) & 255u);
     carry = 0u;                                                                 // multigrid.py:490
     int door = 1;
     const bool inj_gen = p.reset_gen != nullptr;
@@ -437,7 +481,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
         door = 1 + (int)__umulhi(r.y, (uint32_t)(p.W - 3));                     // _rand_int(1, width-2)
       }
       if (split < 1 || split > p.W - 2 || door < 1 || door > p.H - 2) { err |= MG_ERR_BAD_RESPAWN; split = start; door = 1; }
-      for (int j = 0; j < p.H; ++j) g_set(g, g_off(p, split, j), K_WALL);       // vert_wall(split_idx, 0)
+      for (int j = 0; j < p.H; ++j) gs(g_off(p, split, j), K_WALL);       // vert_wall(split_idx, 0)
       spawn_w = split;
     }
     if (p.kind == MG_KIND_CLUTTERED || p.kind == MG_KIND_MEETUP) {
@@ -450,7 +494,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 #pragma unroll 1
       for (int i = 0; i < n_obj; ++i) {
         const uint32_t w = place_dyn<A>(p, g, pd, 0u, i, P_GEN, p.W, inj, inj ? (uint32_t)p.scatter[n * n_obj + i] : 0u, false, gid);
-        g_set(g, g_off(p, aw_x(w), aw_y(w)), i < p.n_goals ? k1 : k2);
+        gs(g_off(p, aw_x(w), aw_y(w)), i < p.n_goals ? k1 : k2);
         err |= w >> 16;
         if (i < p.n_goals) {                       // Meetup goal_pos[i]; Cluttered: the goal the shaper measures to
           if (i == 0) goal[0] = w & AW_POS;
@@ -470,9 +514,9 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       err |= w >> 16;
     }
     if (p.kind == MG_KIND_DOORKEY) {                                            // doorkey.py:58-65
-      g_set(g, g_off(p, spawn_w, door), K_DOOR_YELLOW_LOCKED);
+      gs(g_off(p, spawn_w, door), K_DOOR_YELLOW_LOCKED);
       const uint32_t w = place_dyn<A>(p, g, pd, all, 0, P_KEY, spawn_w, inj_gen, genw >> 16, false, gid);
-      g_set(g, g_off(p, aw_x(w), aw_y(w)), K_KEY_YELLOW);
+      gs(g_off(p, aw_x(w), aw_y(w)), K_KEY_YELLOW);
       err |= w >> 16;
     }
     if (p.kind == MG_KIND_MEETUP) {                                             // MeetupEnv.reset, meetup.py:59-62
@@ -501,16 +545,18 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (__builtin_amdgcn_ballot_w64(dirty) != 0ull) {          // wave-uniform
 #pragma unroll 4
-  for (int k = 0; k < p.GW; ++k) {
-    const int ci = c4 + 4 * k;
-    if (ci < cells) ghbm[k * kWave + lane] = gw[(int)pidx[ci] * kCellW + l4];
+    for (int k = 0; k < p.GW; ++k) {
+      const int ci = c4 + 4 * k;
+      if (ci < cells) ghbm[k * kWave + lane] = gw[(int)pidx[ci] * kCellW + l4];
+    }
   }
 
   // ---- gen_obs (multigrid.py:1037-1067) --------------------------------------------------------
 #if MG_ABL != 2
   if (p.full_obs) {
-    emit_full<A>(p, g, lut, pd, stage, lane, p.obs_full + env0 * (int64_t)(p.W * p.H * 3));
+    emit_full<A>(p, g, reinterpret_cast<const uint8_t*>(gw), lut, cpc, pd, lane, p.obs_full + env0 * (int64_t)(p.W * p.H * 3));
   } else {
 #pragma unroll
     for (int a = 0; a < A; ++a) {
@@ -528,16 +574,17 @@ __global__ __launch_bounds__(256) void mg_dyn_kernel(const Params p) {
   constexpr int ROWB = ViewGeom<V>::ROWB;
   extern __shared__ __align__(16) uint8_t smem[];
   // LDS carve: [stage: nw x 64*ROWB B][grids: nw x (W+2)(H+2)*68 B][distance LUT: LW*LH f64][kind LUT: 256 u32]
-  //            [base: GW u32][pidx: W*H u16]
+  //            [base: GW u32][pidx: W*H u16][cpc: W*H u16]
   const int nw = blockDim.x >> 6;
   const int pcells = (p.W + 2) * (p.H + 2), cells = p.W * p.H;
   uint32_t* stage_all = reinterpret_cast<uint32_t*>(smem);
-  const int stage_b = p.full_obs ? kWave * p.W * p.H * 3 : kWave * ROWB;    // per wave, a multiple of 64
+  const int stage_b = p.full_obs ? 0 : kWave * ROWB;    // per wave; fully observed images are gathered without staging
   uint32_t* grids = reinterpret_cast<uint32_t*>(smem + (size_t)nw * stage_b);
   double* dist = reinterpret_cast<double*>(grids + (size_t)nw * pcells * kCellW + ((nw * pcells * kCellW) & 1));
   uint32_t* lut = reinterpret_cast<uint32_t*>(dist + p.LW * p.LH);
   uint32_t* base = lut + 256;
-  uint16_t* pidx = reinterpret_cast<uint16_t*>(base + p.GW);
+  uint16_t* pidx = reinterpret_cast<uint16_t*>(base + p.GW);   // padded cell index of cell y*W + x
+  uint16_t* cpc = pidx + cells;                                // padded cell index of cell x*H + y (encode() order)
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
 
   // persistent: each wave strides over the 64-env chunks; the first chunk's inputs are requested
@@ -550,7 +597,10 @@ __global__ __launch_bounds__(256) void mg_dyn_kernel(const Params p) {
   for (int i = tid; i < 256; i += blockDim.x) lut[i] = kind_word((uint32_t)i);
   for (int i = tid; i < p.GW; i += blockDim.x) base[i] = p.base_grid[i];
   for (int i = tid; i < p.LW * p.LH; i += blockDim.x) dist[i] = p.dist_lut[i];
-  for (int i = tid; i < cells; i += blockDim.x) pidx[i] = (uint16_t)((i / p.W + 1) * (p.W + 2) + (i % p.W) + 1);
+  for (int i = tid; i < cells; i += blockDim.x) {
+    pidx[i] = (uint16_t)((i / p.W + 1) * (p.W + 2) + (i % p.W) + 1);
+    cpc[i] = (uint16_t)((i % p.H + 1) * (p.W + 2) + (i / p.H) + 1);
+  }
   // every wave's padded grid starts as all grey wall: the ring is never written again
   for (int i = tid; i < nw * pcells * kCellW; i += blockDim.x) grids[i] = K_WALL * 0x01010101u;
   __syncthreads();
@@ -559,25 +609,22 @@ __global__ __launch_bounds__(256) void mg_dyn_kernel(const Params p) {
   uint32_t* gw = grids + (size_t)wv * pcells * kCellW;
   uint32_t err = 0;
   // vector-memory operations a chunk issues after the next chunk's prefetch, all of them for at
-  // least one lane: grid rows, obs stores, env_state, carry, dir_done (rewards in a step on top)
+  // least one lane: obs stores, env_state, carry, dir_done (rewards in a step and dirty grid rows on top)
 #if MG_ABL == 0
   constexpr int kObs = A * ((4 * ROWB + kWave - 1) / kWave);
 #else
   constexpr int kObs = 0;
 #endif
-  constexpr int kLo = (kObs + A + 3) < 63 ? (kObs + A + 3) : 63;               // + GW unknown at compile time
-  constexpr int kHi = (kObs + A + 3 + 16) < 63 ? (kObs + A + 3 + 16) : 63;     // GW == 16 (8x8)
-  constexpr int kFull = A + 3;                                                 // fully observed: at least these
+  constexpr int kLo = (kObs + A + 3) < 63 ? (kObs + A + 3) : 63;   // the grid rows go back only when a lane changed its grid
+  constexpr int kFull = A + 3;                                     // fully observed: at least these
   if (c < p.n_chunks) dyn_wait<A, 0>(cur);
   for (; c < p.n_chunks; c += cstride) {
     const int64_t cn = c + cstride;
     const bool more = cn < p.n_chunks;          // wave-uniform
     if (more) dyn_load<A>(p, cn * kWave, lane, nxt);
-    dyn_chunk<A, V>(p, dist, lut, base, pidx, stage, gw, lane, c * kWave, cur, err);
+    dyn_chunk<A, V>(p, dist, lut, base, pidx, cpc, stage, gw, lane, c * kWave, cur, err);
     if (more) {
-      if (p.full_obs) dyn_wait<A, kFull>(nxt);
-      else if (p.GW == 16) dyn_wait<A, kHi>(nxt);
-      else dyn_wait<A, kLo>(nxt);
+      if (p.full_obs) dyn_wait<A, kFull>(nxt); else dyn_wait<A, kLo>(nxt);
       cur = nxt;
     }
   }

@@ -873,8 +873,8 @@ void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid
 // per CU as LDS allows; persistent over chunks.
 void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* lds_out) {
   const mg_config& c = h->cfg;
-  const size_t rowb = h->full_obs ? (size_t)c.width * c.height * 3 : (size_t)c.view_size * c.view_size * 3;
-  const size_t fixed = ((size_t)h->LW * h->LH * 8 + (size_t)c.width * c.height * 2 + 256 * 4 + (size_t)h->GW * 4 + 8 + 15) / 16 * 16;
+  const size_t rowb = h->full_obs ? 0 : (size_t)c.view_size * c.view_size * 3;   // fully observed images are not staged
+  const size_t fixed = ((size_t)h->LW * h->LH * 8 + (size_t)c.width * c.height * 4 + 256 * 4 + (size_t)h->GW * 4 + 8 + 15) / 16 * 16;
   const size_t per_wave = (size_t)kWave * rowb + (size_t)(c.width + 2) * (c.height + 2) * kCellB;
   int nw = 4;
   while (nw > 1 && (fixed + nw * per_wave > (size_t)kLdsLimit || h->n_chunks < (int64_t)h->n_cu * nw)) nw >>= 1;
