@@ -46,7 +46,7 @@ class AgentNet(nn.Module):
 
   def get_action_and_value(self, image, direction, action=None):
     logits, value = self.forward(image, direction)
-    dist = Categorical(logits=logits)
+    dist = Categorical(logits=logits, validate_args=False)   # argument validation synchronises with the host
     if action is None:
       action = dist.sample()
     return action, dist.log_prob(action), dist.entropy(), value
@@ -103,7 +103,7 @@ def ppo_loss(model, images, directions, actions, old_log_probs, advantages, retu
   """The loss of one epoch of update_agent (v8_robust_ppo.py:326-336).  `model(images, directions)`
   -> (logits, values): an AgentNet or its DistributedDataParallel wrapper (DDP hooks `forward`)."""
   logits, new_values = model(images, directions)
-  dist = Categorical(logits=logits)
+  dist = Categorical(logits=logits, validate_args=False)   # argument validation synchronises with the host
   new_log_probs, entropy = dist.log_prob(actions), dist.entropy()
   ratio = torch.exp(new_log_probs - old_log_probs)
   surr1 = ratio * advantages
@@ -143,9 +143,19 @@ class BatchedController:
     self.optimizers = [torch.optim.Adam(n.parameters(), lr=lr) for n in self.nets]
 
   @torch.no_grad()
-  def rollout(self, n_steps):
+  def rollout(self, n_steps, use_graph=None):
     """run_episode (v8_robust_ppo.py:222-273) for N envs x n_steps, everything on device.
-    Returns per-agent lists of [T, N, ...] tensors."""
+    Returns per-agent lists of [T, N, ...] tensors.
+
+    use_graph (default: on for CUDA devices): the per-step policy work — A forwards, sampling, the action
+    write and the trajectory stores — is launch-bound at these sizes (≈ 60 tiny kernels per step), so it
+    is captured once into two HIP graphs and replayed around the env's own kernel launch: a step is then
+    graph replay + `mg_step` + graph replay.  The returned tensors are the graph's own buffers: they are
+    overwritten by the next graphed rollout of the same length."""
+    if use_graph is None:
+      use_graph = self.device.type == 'cuda'
+    if use_graph:
+      return self._graph_rollout(n_steps)
     env, A, N = self.env, self.n_agents, self.env.n_envs
     buf = {k: [[] for _ in range(A)] for k in ('image', 'direction', 'action', 'log_prob', 'value', 'reward')}
     dones = []
@@ -163,6 +173,56 @@ class BatchedController:
     out = {k: [torch.stack(v[a]) for a in range(A)] for k, v in buf.items()}
     out['done'] = torch.stack(dones)
     return out
+
+  def _graph_rollout(self, n_steps):
+    env, A, N = self.env, self.n_agents, self.env.n_envs
+    cache = self.__dict__.setdefault('_graphs', {})
+    if n_steps not in cache:
+      dev = self.device
+      V = env.view_size
+      buf = {'image': [torch.zeros((n_steps, N, V, V, 3), dtype=torch.uint8, device=dev) for _ in range(A)],
+             'direction': [torch.zeros((n_steps, N), dtype=torch.uint8, device=dev) for _ in range(A)],
+             'action': [torch.zeros((n_steps, N), dtype=torch.long, device=dev) for _ in range(A)],
+             'log_prob': [torch.zeros((n_steps, N), device=dev) for _ in range(A)],
+             'value': [torch.zeros((n_steps, N), device=dev) for _ in range(A)],
+             'reward': [torch.zeros((n_steps, N), device=dev) for _ in range(A)],
+             'done': torch.zeros((n_steps, N), dtype=torch.uint8, device=dev)}
+      t_idx = torch.zeros(1, dtype=torch.long, device=dev)
+
+      def pre():      # policy side of a step: reads the env's obs buffers in place, writes its action buffer
+        for a in range(A):
+          img, d = env.obs_image[a], env.obs_dir[a]
+          act, logp, _, val = self.nets[a].get_action_and_value(img, d)
+          env.actions[:N, a] = act.to(torch.uint8)
+          for k, v in (('image', img), ('direction', d), ('action', act), ('log_prob', logp), ('value', val)):
+            buf[k][a].index_copy_(0, t_idx, v.unsqueeze(0))
+
+      def post():     # after the env kernel: rewards (float32 as at v8:311) and done of the step, then t += 1
+        for a in range(A):
+          buf['reward'][a].index_copy_(0, t_idx, env.reward[a].float().unsqueeze(0))
+        buf['done'].index_copy_(0, t_idx, env.done.unsqueeze(0))
+        t_idx.add_(1)
+
+      side = torch.cuda.Stream(device=dev)
+      side.wait_stream(torch.cuda.current_stream(dev))
+      with torch.cuda.stream(side):     # warm-up outside capture (lazy library initialisation)
+        for _ in range(3):
+          pre()
+          t_idx.zero_()
+      torch.cuda.current_stream(dev).wait_stream(side)
+      g_pre, g_post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g_pre):
+        pre()
+      with torch.cuda.graph(g_post):
+        post()
+      cache[n_steps] = (g_pre, g_post, buf, t_idx)
+    g_pre, g_post, buf, t_idx = cache[n_steps]
+    t_idx.zero_()
+    for _ in range(n_steps):
+      g_pre.replay()
+      env.step()          # one launch on the same stream, outside the graphs: its Philox step index is a kernel argument
+      g_post.replay()
+    return buf
 
   def update(self, traj, epochs=4, max_grad_norm=0.5):
     """update_agent (v8_robust_ppo.py:295-345) for every agent; returns mean loss per agent."""

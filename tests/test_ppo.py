@@ -201,3 +201,38 @@ def test_gpu_rollout_update_on_device_env():
   env2 = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', 2048, seed=1)
   env2.reset()
   assert torch.equal(traj['image'][1][0], env2.obs_image[1])
+
+
+@pytest.mark.gpu
+def test_graph_rollout_is_self_consistent():
+  """The HIP-graph rollout stores exactly what happened: replaying its stored actions through a second env with
+  the same seed reproduces its stored obs / rewards / done, and the nets recompute its stored log-probs and values."""
+  torch = pytest.importorskip('torch')
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  import multigrid_amd
+  from multigrid_amd import ppo
+  n, T = 512, 40
+  env = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', n, seed=21)
+  env.reset()
+  ctl = ppo.BatchedController(env, ddp=False, seed=3)
+  traj = ctl.rollout(T, use_graph=True)
+  twin = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', n, seed=21)
+  twin.reset()
+  for t in range(T):
+    for a in range(3):
+      assert torch.equal(traj['image'][a][t], twin.obs_image[a]), (t, a)
+      assert torch.equal(traj['direction'][a][t], twin.obs_dir[a]), (t, a)
+      _, logp, _, val = ctl.nets[a].get_action_and_value(twin.obs_image[a], twin.obs_dir[a], traj['action'][a][t])
+      assert torch.allclose(logp, traj['log_prob'][a][t], atol=1e-5) and torch.allclose(val, traj['value'][a][t], atol=1e-5)
+    acts = torch.stack([traj['action'][a][t] for a in range(3)])
+    assert int(acts.min()) >= 0 and int(acts.max()) <= 6
+    twin.step(acts)
+    for a in range(3):
+      assert torch.equal(traj['reward'][a][t], twin.reward[a].float()), (t, a)
+    assert torch.equal(traj['done'][t], twin.done), t
+  # a second graphed rollout continues from where the first stopped, and an update runs on its output
+  traj = ctl.rollout(T, use_graph=True)
+  losses = ctl.update(traj, epochs=1)
+  assert all(np.isfinite(l) for l in losses)
+  env.close(); twin.close()

@@ -16,6 +16,7 @@ def main():
   ap.add_argument('--envs', type=int, default=16384)
   ap.add_argument('--steps', type=int, default=100)
   ap.add_argument('--iters', type=int, default=3)
+  ap.add_argument('--no-graph', action='store_true', help='eager rollout (one launch per torch op)')
   args = ap.parse_args()
   import torch
   import multigrid_amd
@@ -23,12 +24,13 @@ def main():
   env = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', args.envs, seed=0)
   env.reset()
   ctl = ppo.BatchedController(env, ddp=False)
-  ctl.update(ctl.rollout(args.steps))            # warm-up (MIOpen/hipBLASLt heuristics)
+  graph = not args.no_graph
+  ctl.update(ctl.rollout(args.steps, use_graph=graph))            # warm-up (MIOpen/hipBLASLt heuristics, graph capture)
   torch.cuda.synchronize()
   tr = tu = 0.0
   for _ in range(args.iters):
     t0 = time.perf_counter()
-    traj = ctl.rollout(args.steps)
+    traj = ctl.rollout(args.steps, use_graph=graph)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     ctl.update(traj)
@@ -37,7 +39,7 @@ def main():
     tr += t1 - t0
     tu += t2 - t1
   n = args.envs * 3 * args.steps * args.iters
-  print(json.dumps({'envs': args.envs, 'steps': args.steps, 'rollout_agent_steps_per_s': n / tr,
+  print(json.dumps({'hip_graph_rollout': graph, 'envs': args.envs, 'steps': args.steps, 'rollout_agent_steps_per_s': n / tr,
                     'end_to_end_agent_steps_per_s': n / (tr + tu), 'rollout_s': tr / args.iters, 'update_s': tu / args.iters,
                     'reference_v8_end_to_end_agent_steps_per_s': 1.6e3}))
 
