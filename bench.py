@@ -86,6 +86,8 @@ def main():
   ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N>1 (nccl = RCCL); gloo only to rehearse on one GPU')
   ap.add_argument('--all-on-device0', action='store_true', help='rehearsal: every rank uses cuda:0')
   ap.add_argument('--cpu-seconds', type=float, default=12.0)
+  ap.add_argument('--env-id', default=ENV_ID, help='any registered id; anything but the default is a side measurement '
+                  '(mutable-grid kernel: DoorKey / Meetup / random Cluttered), not the BASELINE metric')
   args = ap.parse_args()
 
   import torch
@@ -111,8 +113,15 @@ def main():
   dev = torch.device('cuda', local_rank)
 
   base, n = shard.shard_range(rank, world, args.envs)
-  env = multigrid_amd.make_batched(ENV_ID, n, device=local_rank, seed=0xC0FFEE, env_id_base=base,
+  env = multigrid_amd.make_batched(args.env_id, n, device=local_rank, seed=0xC0FFEE, env_id_base=base,
                                    shaping='v8', auto_reset=True)
+  headline = args.env_id == ENV_ID
+  A, V = env.n_agents, env.view_size
+  # bytes one env-step has to move: obs + dir/done + f64 rewards + actions + env_state r/w,
+  # and for per-env grids: carry r/w + grid rows r/w (+ aux r/w)
+  b_alg = B_ALG_PER_ENV_STEP if headline else (
+      (env.width * env.height * 3 if env.obs_full is not None else A * V * V * 3) + (4 if A < 4 else 8) + 8 * A + 4 +
+      8 * (A + 1) + ((8 + 8 * env.grid_words) if env.mutable_grid else 0) + (32 if env.aux is not None else 0))
   gen = torch.Generator(device=dev)
   gen.manual_seed(1234 + rank)
   ring = torch.randint(0, 7, (ACTION_RING, env.stride, 4), dtype=torch.uint8, device=dev, generator=gen)
@@ -145,22 +154,23 @@ def main():
   errs = env.check_errors()
 
   if rank == 0:
-    achieved = B_ALG_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
+    achieved = b_alg * n / (kernel_ms * 1e-3) / 1e9
     out = {
-        'metric': 'env agent-steps/sec (whole node) Cluttered-15x15 3 agents; % HBM roofline',
+        'metric': 'env agent-steps/sec (whole node) Cluttered-15x15 3 agents; % HBM roofline' if headline else
+                  'env agent-steps/sec, side measurement on %s (not the BASELINE metric)' % args.env_id,
         'value': value, 'unit': 'agent-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8 obs/state + f64 rewards', 'data': 'synthetic',
-        'config': {'workload': '%s, 3 agents, view 5, v8 shaping + auto-reset fused, %d envs per GPU, '
-                               'uniform random actions resident in HBM' % (ENV_ID, n),
+        'config': {'workload': '%s, %d agents, view %d, v8 shaping + auto-reset fused, %d envs per GPU, '
+                               'uniform random actions resident in HBM' % (args.env_id, A, V, n),
                    'envs_per_gpu': n, 'global_envs': n * world, 'parallelism': 'env-sharded x%d, no collective in step' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(n),
-                     'kernel': 'mg_kernel<3,5,table,fast>', 'kernel_ms': kernel_ms, 'launch': env.launch_info(),
-                     'alg_bytes_per_launch': B_ALG_PER_ENV_STEP * n},
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(n) if headline else None,
+                     'kernel': 'mg_kernel<3,5,%s,fast>' % env.launch_info()['path'] if headline else 'mg_dyn_kernel<%d,%d>' % (A, V),
+                     'kernel_ms': kernel_ms, 'launch': env.launch_info(), 'alg_bytes_per_launch': b_alg * n},
         'device_errors': errs,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and headline:
       out['cpu_baseline'] = cpu_baseline(env.cells, args.cpu_seconds)
     print(json.dumps(out), flush=True)
   env.close()
