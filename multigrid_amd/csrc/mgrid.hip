@@ -344,9 +344,11 @@ __device__ __forceinline__ void emit_obs(uint64_t pd, int a, uint32_t (&s)[ViewG
 // those stores (wait_chunk).  Nothing is computed from the registers before that wait.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct ChunkIn {
-  u32x4 q;          // A == 3: the four env_state words
-  uint32_t w[5];    // other A: env_state words, compile-time indices only
-  uint32_t act;     // the env's four action bytes, as loaded
+  u32x4 q;                       // A == 3: the four env_state words
+  uint32_t w0, w1, w2, w3, w4;   // other A: env_state words (scalars, not an array: an array member made hipcc keep the
+                                 // launch-resident batch's ChunkIn[] in scratch and store the registers there while
+                                 // their loads were still in flight — tools/isa_prefetch_lint.py)
+  uint32_t act;                  // the env's four action bytes, as loaded
 };
 
 __device__ __forceinline__ uint32_t asm_load_u32(const void* ptr) {
@@ -362,15 +364,18 @@ template <int A, bool FAST>
 __device__ __forceinline__ void load_chunk(const Params& p, int64_t env0, int lane, ChunkIn& in) {
   const int64_t n = env0 + lane;
   in.q = u32x4{0, 0, 0, 0};
-#pragma unroll
-  for (int a = 0; a < 5; ++a) in.w[a] = 0u;
+  in.w0 = in.w1 = in.w2 = in.w3 = in.w4 = 0u;
   in.act = 0x06060606u;
   if (A == 3) {
     const void* ptr = reinterpret_cast<const uint4*>(p.env_state) + n;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(in.q) : "v"(ptr) : "memory");
   } else {
-#pragma unroll
-    for (int a = 0; a <= A; ++a) in.w[a] = asm_load_u32(p.env_state + n * (A + 1) + a);
+    const uint32_t* sp = p.env_state + n * (A + 1);
+    in.w0 = asm_load_u32(sp);
+    if (A >= 1) in.w1 = asm_load_u32(sp + 1);
+    if (A >= 2) in.w2 = asm_load_u32(sp + 2);
+    if (A >= 3) in.w3 = asm_load_u32(sp + 3);
+    if (A >= 4) in.w4 = asm_load_u32(sp + 4);
   }
   if (FAST || (p.op == OP_STEP && !p.random_actions)) in.act = asm_load_u32(p.actions + n);
 }
@@ -380,7 +385,7 @@ __device__ __forceinline__ void load_chunk(const Params& p, int64_t env0, int la
 template <int K>
 __device__ __forceinline__ void wait_chunk(ChunkIn& in) {
   asm volatile("s_waitcnt vmcnt(%7)"
-               : "+v"(in.q), "+v"(in.w[0]), "+v"(in.w[1]), "+v"(in.w[2]), "+v"(in.w[3]), "+v"(in.w[4]),
+               : "+v"(in.q), "+v"(in.w0), "+v"(in.w1), "+v"(in.w2), "+v"(in.w3), "+v"(in.w4),
                  "+v"(in.act)
                : "n"(K)
                : "memory");
@@ -491,8 +496,7 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
   uint32_t win[5];
   if (A == 3) { win[0] = in.q.x; win[1] = in.q.y; win[2] = in.q.z; win[3] = in.q.w; win[4] = 0u; }
   else {
-#pragma unroll
-    for (int a = 0; a < 5; ++a) win[a] = in.w[a];
+    win[0] = in.w0; win[1] = in.w1; win[2] = in.w2; win[3] = in.w3; win[4] = in.w4;
   }
   uint32_t actw = 0, st = win[A], err = 0;
 #pragma unroll
@@ -667,7 +671,11 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
   constexpr int kObs = 0;
 #endif
   constexpr int kStep = (kObs + 2 + A) < 63 ? (kObs + 2 + A) : 63, kReset = (kObs + 2) < 63 ? (kObs + 2) : 63;
-  if (FAST && p.n_chunks <= cstride * kUpfront) {
+  // (only for the benchmark shape: for larger bodies hipcc does not unroll the loops below, indexes in[] at run
+  // time, keeps it in scratch and would store the registers there while their loads are still in flight —
+  // tools/isa_prefetch_lint.py, run by tests/test_isa_lint.py, checks every kernel for that)
+  constexpr bool kCanUpfront = A == 3 && V == 5;
+  if (FAST && kCanUpfront && p.n_chunks <= cstride * kUpfront) {
     // Launch-resident batch (at most kUpfront chunks per wave): fetch ALL inputs first, then only
     // store.  The whole chip then runs one read burst followed by an uninterrupted write stream,
     // which the memory system serves faster than reads interleaved with writes.

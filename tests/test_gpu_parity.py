@@ -376,3 +376,29 @@ def test_full_size_fast_vs_general_instantiation():
       assert torch.equal(fast.env_state, gen.env_state), t
   assert bool(fast.done.all().item()) is False and int(fast.step_count.max().item()) == 4
   assert fast.check_errors() == 0 and gen.check_errors() == 0
+
+
+@pytest.mark.parametrize('A,V,n,grid', [(4, 5, 3000, None), (2, 7, 3000, None), (3, 7, 3000, None), (1, 5, 3000, None),
+                                        (3, 7, 20000, 2), (4, 5, 20000, 3), (3, 3, 20000, 2)])
+def test_fast_instantiation_other_shapes(empty_cells, monkeypatch, A, V, n, grid):
+  """The FAST instantiation (no env_reward output, free-running step) of every other (n_agents, view_size) the
+  library instantiates, on launch-resident and on many-chunks-per-wave batches."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  if grid is not None:
+    monkeypatch.setenv('MG_DEBUG_GRID', str(grid))
+    monkeypatch.setenv('MG_DEBUG_NW', '4')
+  env = BatchedMultiGrid(empty_cells, n_envs=n, n_agents=A, view_size=V, seed=91)     # no env_reward => FAST
+  orc = c_oracle.OracleBatch(empty_cells, n, A=A, V=V, shaping=1, auto_reset=1, seed=91)
+  rng = np.random.RandomState(91)
+  env.reset()
+  orc.reset()
+  for t in range(60):
+    act = rng.randint(0, 7, size=(A, orc.stride)).astype(np.uint8)
+    act[rng.rand(A, orc.stride) < 0.35] = 2
+    env.step(torch.from_numpy(act).to(env.device))
+    orc.step(act)
+    if t % 6 == 0 or t > 55:
+      _cmp_step(env, orc, 'fast (%d,%d) step %d' % (A, V, t))
+  assert env.check_errors() == 0
+  env.close()
