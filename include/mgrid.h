@@ -75,6 +75,10 @@ extern "C" {
 #define MG_KIND_DOORKEY   1
 #define MG_KIND_CLUTTERED 2
 #define MG_KIND_MEETUP    3
+#define MG_KIND_FOURROOMS 4   /* FourRoomsEnv._gen_grid with two_rooms=False, random agents and goal (multigrid_envs/
+                                 fourrooms.py:53-104): walls at x = W/2 and y = H/2 with one random gap per segment, drawn per
+                                 env and per reset; the goal is placed after the agents.  Injected as three scatter pairs:
+                                 (gap_top_y, gap_left_x), (gap_right_x, gap_bottom_y), (goal_x, goal_y). */
 #define MG_GEN_LAVA 1      /* gen_flags: Cluttered walls_are_lava */
 #define MG_MAX_SCATTER 64  /* gen_n_goals + gen_n_clutter */
 
@@ -159,8 +163,10 @@ typedef struct mg_buffers {
                             LDS address is linear in the cell index; use mg_export_grid for a plain [n][H*W] copy. */
   int32_t  grid_words;   /* ceil(W*H/4) */
   int32_t  mutable_grid;
-  uint32_t* aux;         /* MEETUP only, [env_stride][4]: words 0..2 = MeetupEnv.goal_pos[k] as x | y<<6 (0xFFFFFFFF if
-                            unused), word 3 = past_goal_dist, one byte per agent (meetup.py:61,70,94) */
+  uint32_t* aux;         /* MEETUP, CLUTTERED, FOURROOMS, [env_stride][4]: words 0..2 = MeetupEnv.goal_pos[k] as x | y<<6
+                            (0xFFFFFFFF if unused), word 3 = past_goal_dist, one byte per agent (meetup.py:61,70,94);
+                            CLUTTERED with a scattered goal / FOURROOMS: word 0 = the env's goal cell (what the v8
+                            shaper's get_goal_position finds, v8_robust_ppo.py:159-169) */
   uint8_t* obs_full;     /* fully observed kinds (MEETUP) only, [env_stride][W*H*3]: Grid.encode() of the whole grid,
                             [x][y][(type,color,state)] with the agents in their cells as (10, id, dir); the same image
                             for every agent (multigrid.py:1043-1045), obs['position'][a] is in env_state.  obs_image is
@@ -222,8 +228,8 @@ int mg_reset_inject_dyn(mg_handle* h, const uint8_t* env_mask, const int8_t* spa
 int mg_step_replay_dyn(mg_handle* h, const void* actions, const uint8_t* order, const int8_t* respawn,
                        const int8_t* objdrop, const int8_t* reset_spawn, const int8_t* reset_gen);
 
-/* Reset of the scatter kinds (CLUTTERED, MEETUP) with the layout the reference drew injected: scatter = device
- * int8[env_stride][gen_n_goals + gen_n_clutter][2] = the (x, y) place_obj accepted for every scattered object in
+/* Reset of the scatter kinds (CLUTTERED, MEETUP; FOURROOMS with its three pairs) with the layout the reference drew
+ * injected: scatter = device int8[env_stride][gen_n_goals + gen_n_clutter][2] = the (x, y) place_obj accepted for every scattered object in
  * draw order (goal / goal doors first, then the clutter; cluttered.py:28-36, meetup.py:67-72); spawn as in
  * mg_reset_inject.  Either pointer may be NULL (drawn on device).  Auto-resets inside step always draw on device. */
 int mg_reset_inject_scatter(mg_handle* h, const uint8_t* env_mask, const int8_t* spawn, const int8_t* scatter);

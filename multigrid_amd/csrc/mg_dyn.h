@@ -1,4 +1,5 @@
-// mg_dyn.h — the mutable-grid kernel: DoorKey and fixed layouts that hold keys,
+// mg_dyn.h — the mutable-grid kernel: every env kind whose grid differs between envs —
+// DoorKey, Meetup, Cluttered / FourRooms with layouts drawn per env, and fixed layouts that hold keys,
 // balls, boxes, doors or floor tiles.  Included by mgrid.hip inside its anonymous namespace; shares
 // Params, Philox, the agent-order / action draws, the v8 shaper and the obs staging with the
 // shared-map kernel.
@@ -447,7 +448,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       out_rew[a] = rew[a];
       if (p.shaping == MG_SHAPING_V8) {
         // get_goal_position (v8:159-169): the per-env scattered goal of a Cluttered layout, else the handle's
-        const bool own = p.kind == MG_KIND_CLUTTERED && p.n_goals != 0;
+        const bool own = (p.kind == MG_KIND_CLUTTERED && p.n_goals != 0) || p.kind == MG_KIND_FOURROOMS;
         const int gx = own ? (int)(goal[0] & 63u) : p.gx, gy = own ? (int)((goal[0] >> 6) & 63u) : p.gy;
         shw[a] = v8_shape<true>(p, dist, shw[a], pd_get(pd, a), (actw >> (3 * a)) & 7u, rew[a], out_rew[a], gx, gy);
       }
@@ -505,6 +506,31 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 #pragma unroll
       for (int i = 0; i < 3; ++i) if (i >= p.n_goals) goal[i] = 0xFFFFFFFFu;
     }
+    if (p.kind == MG_KIND_FOURROOMS) {
+      // FourRoomsEnv._gen_grid (fourrooms.py:63-90): walls at x = W/2 and y = H/2 with one gap per segment, drawn
+      // in the order top, left, right, bottom; a gap at x <= 1, x >= W-1, y <= 0 or y >= H-1 is not carved
+      const int rw = p.W / 2, rh = p.H / 2;
+      int g0, g1, g2, g3;                                                       // top y, left x, right x, bottom y
+      if (p.scatter) {
+        const uint32_t w0 = p.scatter[n * 3], w1 = p.scatter[n * 3 + 1];
+        g0 = (int8_t)(w0 & 255u); g1 = (int8_t)(w0 >> 8); g2 = (int8_t)(w1 & 255u); g3 = (int8_t)(w1 >> 8);
+      } else {
+        const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), (uint32_t)P_GEN << 28, p.seed_lo, p.seed_hi);
+        g0 = 1 + (int)__umulhi(r.x, (uint32_t)(rh - 1));
+        g1 = 1 + (int)__umulhi(r.y, (uint32_t)(rw - 1));
+        g2 = rw + 1 + (int)__umulhi(r.z, (uint32_t)(rw - 1));
+        g3 = rh + 1 + (int)__umulhi(r.w, (uint32_t)(rh - 1));
+      }
+      if (g0 < 1 || g0 >= rh || g1 < 1 || g1 >= rw || g2 <= rw || g2 >= 2 * rw || g3 <= rh || g3 >= 2 * rh) {
+        err |= MG_ERR_BAD_RESPAWN; g0 = 1; g1 = 1; g2 = rw + 1; g3 = rh + 1;
+      }
+      for (int y = 0; y < 2 * rh; ++y) gs(g_off(p, rw, y), K_WALL);
+      for (int x = 0; x < 2 * rw; ++x) gs(g_off(p, x, rh), K_WALL);
+      if (g0 < p.H - 1) gs(g_off(p, rw, g0), 0u);                               // x = rw is never <= 1 for W >= 6
+      if (g1 > 1) gs(g_off(p, g1, rh), 0u);
+      if (g2 < p.W - 1) gs(g_off(p, g2, rh), 0u);
+      if (g3 < p.H - 1) gs(g_off(p, rw, g3), 0u);
+    }
 #pragma unroll 1
     for (int a = 0; a < A; ++a) {                                               // place_agent, in agent order
       const bool inj = p.reset_spawn != nullptr;
@@ -518,6 +544,13 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       const uint32_t w = place_dyn<A>(p, g, pd, all, 0, P_KEY, spawn_w, inj_gen, genw >> 16, false, gid);
       gs(g_off(p, aw_x(w), aw_y(w)), K_KEY_YELLOW);
       err |= w >> 16;
+    }
+    if (p.kind == MG_KIND_FOURROOMS) {                                          // place_obj(Goal()) after the agents, fourrooms.py:104
+      const bool inj = p.scatter != nullptr;
+      const uint32_t w = place_dyn<A>(p, g, pd, all, 1, P_GEN, p.W, inj, inj ? (uint32_t)p.scatter[n * 3 + 2] : 0u, false, gid);
+      gs(g_off(p, aw_x(w), aw_y(w)), K_GOAL);
+      err |= w >> 16;
+      goal[0] = w & AW_POS; goal[1] = goal[2] = 0xFFFFFFFFu;
     }
     if (p.kind == MG_KIND_MEETUP) {                                             // MeetupEnv.reset, meetup.py:59-62
       uint32_t sum;

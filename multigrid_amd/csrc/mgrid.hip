@@ -1000,7 +1000,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (c.kernel_path < MG_PATH_AUTO || c.kernel_path > MG_PATH_TABLE) return fail(MG_EINVAL, "unknown kernel_path");
   if (c.env_id_base < 0 || (uint64_t)c.env_id_base + (uint64_t)c.n_envs > 0xFFFFFFFFull)
     return fail(MG_EINVAL, "global env ids must fit 32 bits");
-  if (c.env_kind < MG_KIND_STATIC || c.env_kind > MG_KIND_MEETUP) return fail(MG_EINVAL, "unknown env_kind");
+  if (c.env_kind < MG_KIND_STATIC || c.env_kind > MG_KIND_FOURROOMS) return fail(MG_EINVAL, "unknown env_kind");
   const Variant* var = nullptr;
   for (const Variant& v : kVariants)
     if (v.A == c.n_agents && v.V == c.view_size) var = &v;
@@ -1015,6 +1015,8 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
     if (c.kernel_path == MG_PATH_TABLE) return fail(MG_EUNSUPPORTED, "no table kernel for mutable grids");
     if (c.env_kind == MG_KIND_DOORKEY) {
       if (c.width != c.height || c.width < 5) return fail(MG_EINVAL, "DoorKey needs a square grid of size >= 5");
+    } else if (c.env_kind == MG_KIND_FOURROOMS) {
+      if (c.width < 6 || c.height < 6) return fail(MG_EINVAL, "FourRooms needs a grid of at least 6x6");
     } else {
       const int interior = (c.width - 2) * (c.height - 2);
       if (c.gen_n_clutter < 0 || c.gen_n_goals < 0 || c.gen_n_goals + c.gen_n_clutter > MG_MAX_SCATTER)
@@ -1069,7 +1071,8 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (rc == MG_OK) rc = dalloc(h, &h->err, 1);
   if (rc == MG_OK && !h->full_obs) rc = dalloc(h, &h->buf.obs_image, A * S * rowb);
   if (rc == MG_OK && h->full_obs) rc = dalloc(h, &h->obs_full, S * (size_t)c.width * c.height * 3);
-  if (rc == MG_OK && (c.env_kind == MG_KIND_MEETUP || c.env_kind == MG_KIND_CLUTTERED)) rc = dalloc(h, &h->aux, S * 4);
+  if (rc == MG_OK && (c.env_kind == MG_KIND_MEETUP || c.env_kind == MG_KIND_CLUTTERED || c.env_kind == MG_KIND_FOURROOMS))
+    rc = dalloc(h, &h->aux, S * 4);
   if (rc == MG_OK) rc = dalloc(h, &h->buf.reward, A * S);
   if (rc == MG_OK && c.emit_env_reward) rc = dalloc(h, &h->buf.env_reward, A * S);
   if (rc == MG_OK) rc = dalloc(h, &h->buf.dir_done, S * (size_t)h->dd_bytes);
@@ -1274,8 +1277,8 @@ int mg_step_replay_dyn(mg_handle* h, const void* actions, const uint8_t* order, 
 
 int mg_reset_inject_scatter(mg_handle* h, const uint8_t* env_mask, const int8_t* spawn, const int8_t* scatter) {
   if (!h) return fail(MG_EINVAL, "null handle");
-  if (h->cfg.env_kind != MG_KIND_CLUTTERED && h->cfg.env_kind != MG_KIND_MEETUP)
-    return fail(MG_EINVAL, "scatter injection is for the CLUTTERED / MEETUP kinds");
+  if (h->cfg.env_kind != MG_KIND_CLUTTERED && h->cfg.env_kind != MG_KIND_MEETUP && h->cfg.env_kind != MG_KIND_FOURROOMS)
+    return fail(MG_EINVAL, "scatter injection is for the CLUTTERED / MEETUP / FOURROOMS kinds");
   int rc = launch(h, OP_RESET, nullptr, nullptr, nullptr, spawn, env_mask, 0, nullptr, nullptr, nullptr, scatter);
   if (rc == MG_OK) h->have_reset = true;
   return rc;

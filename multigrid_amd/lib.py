@@ -9,8 +9,9 @@ MG_OK = 0
 SHAPING_NONE, SHAPING_V8 = 0, 1
 PATH_AUTO, PATH_GENERIC, PATH_TABLE = 0, 1, 2
 ERR_BAD_ACTION, ERR_BAD_RESPAWN, ERR_BAD_ORDER, ERR_MISSING_DRAW = 1, 2, 4, 8
-KIND_STATIC, KIND_DOORKEY, KIND_CLUTTERED, KIND_MEETUP = 0, 1, 2, 3
-KINDS = {'static': KIND_STATIC, 'doorkey': KIND_DOORKEY, 'cluttered': KIND_CLUTTERED, 'meetup': KIND_MEETUP}
+KIND_STATIC, KIND_DOORKEY, KIND_CLUTTERED, KIND_MEETUP, KIND_FOURROOMS = 0, 1, 2, 3, 4
+KINDS = {'static': KIND_STATIC, 'doorkey': KIND_DOORKEY, 'cluttered': KIND_CLUTTERED, 'meetup': KIND_MEETUP,
+         'fourrooms': KIND_FOURROOMS}
 GEN_LAVA = 1
 
 

@@ -117,7 +117,7 @@ class Recorder:
     for a, x, y, d in self._agents[-A:]:
       spawn[a] = (x, y, d, 0)
     scatter = np.array([[x, y] for (_, x, y) in self._objects], np.int8).reshape(-1, 2)
-    if self.kind not in ('cluttered', 'meetup'):
+    if self.kind not in ('cluttered', 'meetup'):       # (fourrooms gaps are not place_obj calls: not recordable this way)
       scatter = np.zeros((0, 2), np.int8)
     out = dict(spawn=spawn, gen=self._gen(), scatter=scatter, actions=[], order=[], respawn=[], objdrop=[], env_reward=[], shaped_reward=[],
                done=[], obs_image=[np.stack(obs['image'])], obs_dir=[np.array(obs['direction'], np.uint8)])

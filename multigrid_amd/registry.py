@@ -30,6 +30,13 @@ register('MultiGrid-Cluttered-Fixed-15x15', dict(
     layout=layouts.cluttered_fixed_15x15, n_agents=3, view_size=5, max_steps=100,
     see_through_walls=False, competitive=False))
 
+# EmptyEnv with agent_start='random' (multigrid_envs/empty.py:28-60, 106-117): border walls, goal at (size-2, size-2),
+# agents anywhere, view 5, see_through_walls=True, max_steps 2*size^2 — a static layout.  The fixed-start ids
+# (agents always re-placed on their start cells, empty.py:80-89) are not registered.
+for _id, _size, _agents in (('MultiGrid-Empty-Random-5x5-v0', 5, 2), ('MultiGrid-Empty-Random-8x8-v0', 8, 3)):
+  register(_id, dict(layout=(lambda n=_size: layouts.empty_bordered(n, n, goal=(n - 2, n - 2))), n_agents=_agents, view_size=5,
+                     max_steps=2 * _size * _size, see_through_walls=True, competitive=False))
+
 # DoorKeyEnv family (multigrid_envs/doorkey.py:27-161): view 7 (multigrid.py:333 default),
 # max_steps 10*size^2, layouts drawn per env and per reset on device.  The 16x16 five-agent id is
 # not registered: the kernels pack at most four agents.
@@ -46,6 +53,13 @@ for _id, _size, _agents, _clutter, _steps in (('MultiGrid-Cluttered-v0', 15, 3, 
                                              ('MultiGrid-Cluttered-Single-6x6-v0', 6, 1, 5, 50)):
   register(_id, dict(kind='cluttered', size=_size, n_agents=_agents, view_size=5, max_steps=_steps, n_goals=1,
                      n_clutter=_clutter, see_through_walls=False, competitive=False))
+
+# FourRoomsEnv (multigrid_envs/fourrooms.py:25-134): max_steps 100, gaps / agents / goal drawn per reset.  The default
+# 19x19 id has five agents (not instantiated); the *-Minigrid-* and TwoRooms ids are not listed.
+register('MultiGrid-FourRooms-15x15-v0', dict(kind='fourrooms', size=15, n_agents=3, view_size=5, max_steps=100,
+                                              see_through_walls=False, competitive=False))
+register('MultiGrid-FourRooms-Single-v0', dict(kind='fourrooms', size=19, n_agents=1, view_size=7, max_steps=100,
+                                               see_through_walls=False, competitive=False))
 
 # MeetupEnv family (multigrid_envs/meetup.py:26-236): fully observed, view size unused (default 7), max_steps 250.
 # MultiGrid-Meetup-Multi-12x12-v0 (5 goals) is not registered: the kernel keeps at most three goal doors.

@@ -90,8 +90,9 @@ def lib():
   return _LIB
 
 
-KIND_STATIC, KIND_DOORKEY, KIND_CLUTTERED, KIND_MEETUP = 0, 1, 2, 3
-KINDS = {'static': KIND_STATIC, 'doorkey': KIND_DOORKEY, 'cluttered': KIND_CLUTTERED, 'meetup': KIND_MEETUP}
+KIND_STATIC, KIND_DOORKEY, KIND_CLUTTERED, KIND_MEETUP, KIND_FOURROOMS = 0, 1, 2, 3, 4
+KINDS = {'static': KIND_STATIC, 'doorkey': KIND_DOORKEY, 'cluttered': KIND_CLUTTERED, 'meetup': KIND_MEETUP,
+         'fourrooms': KIND_FOURROOMS}
 MAXOBJ = 64
 
 
@@ -154,7 +155,7 @@ class OracleEnv:
     if not self.h:
       raise ValueError('bad oracle config')
     _configure(self.L, self.h, kind, n_goals, n_clutter, lava)
-    self.n_obj = (n_goals + n_clutter) if kind in ('cluttered', 'meetup') else 0
+    self.n_obj = (n_goals + n_clutter) if kind in ('cluttered', 'meetup') else (3 if kind == 'fourrooms' else 0)
     self.full = kind == 'meetup'
     self.img_shape = (W, H, 3) if self.full else (V, V, 3)
     if cells is not None:
@@ -285,7 +286,7 @@ class OracleBatch:
                shaping=0, auto_reset=0, seed=0, gid_base=0, kind='static', n_goals=0, n_clutter=0, lava=False):
     self.L = lib()
     self.n, self.A, self.V, self.W, self.H = n, A, V, W, H
-    self.n_obj = (n_goals + n_clutter) if kind in ('cluttered', 'meetup') else 0
+    self.n_obj = (n_goals + n_clutter) if kind in ('cluttered', 'meetup') else (3 if kind == 'fourrooms' else 0)
     self.stride = (n + 63) // 64 * 64
     if cells is not None:
       cells = np.ascontiguousarray(cells, dtype=np.uint8).reshape(W * H * 3)

@@ -86,7 +86,7 @@ static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
 void mgo_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
 
 enum { P_ORDER = 0, P_RESPAWN = 1, P_SPAWN = 2, P_ACTION = 3, P_GEN = 4, P_KEY = 5, P_OBJDROP = 6 };
-enum { KIND_STATIC = 0, KIND_DOORKEY = 1, KIND_CLUTTERED = 2, KIND_MEETUP = 3 };
+enum { KIND_STATIC = 0, KIND_DOORKEY = 1, KIND_CLUTTERED = 2, KIND_MEETUP = 3, KIND_FOURROOMS = 4 };
 #define MAXOBJ 64              /* objects a scatter generator places (goals/doors + clutter) */
 #define MAXGOALS 3
 #define MAX_ATTEMPTS 256
@@ -460,11 +460,57 @@ static void gen_scatter(mgo_env* e) {
   if (e->kind == KIND_MEETUP) meetup_dist(e, e->past_dist);       /* MeetupEnv.reset meetup.py:59-62 */
 }
 
+/* FourRoomsEnv._gen_grid with two_rooms=False and random agents / goal (multigrid_envs/fourrooms.py:53-104):
+ * border walls, a vertical wall at x = W//2 and a horizontal wall at y = H//2, one gap per wall segment
+ * (drawn in the order top, left, right, bottom; a gap at x <= 1, x >= W-1, y <= 0 or y >= H-1 is not carved,
+ * :79-80,88-89), then the agents, then the goal by place_obj.  Recorded / injected as three (a, b) pairs:
+ * (gap_top_y, gap_left_x), (gap_right_x, gap_bottom_y), (goal_x, goal_y). */
+static void gen_fourrooms(mgo_env* e) {
+  const int W = e->W, H = e->H, rw = W / 2, rh = H / 2;
+  const obj_t wall = {T_WALL, C_GREY, 0, 0}, goal = {T_GOAL, C_GREEN, 0, 0};
+  for (int j = 0; j < H; ++j)
+    for (int i = 0; i < W; ++i)                          /* horz_wall / vert_wall around the grid :58-61 */
+      grid_set(&e->grid, i, j, (i == 0 || j == 0 || i == W - 1 || j == H - 1) ? wall : NONE);
+  int g[4];                                              /* top y, left x, right x, bottom y */
+  if (e->inj_scatter) { g[0] = e->inj_scatter[0]; g[1] = e->inj_scatter[1]; g[2] = e->inj_scatter[2]; g[3] = e->inj_scatter[3]; }
+  else {
+    uint32_t r[4];
+    draw_words(e, P_GEN, 0, 0, r);
+    g[0] = 1 + (int)mulhi32(r[0], (uint32_t)(rh - 1));           /* _rand_int(y_top + 1, y_bottom), j = 0   :77 */
+    g[1] = 1 + (int)mulhi32(r[1], (uint32_t)(rw - 1));           /* _rand_int(x_left + 1, x_right), i = 0   :86 */
+    g[2] = rw + 1 + (int)mulhi32(r[2], (uint32_t)(rw - 1));      /* i = 1 */
+    g[3] = rh + 1 + (int)mulhi32(r[3], (uint32_t)(rh - 1));      /* j = 1 */
+  }
+  if (g[0] < 1 || g[0] >= rh || g[1] < 1 || g[1] >= rw || g[2] <= rw || g[2] >= 2 * rw || g[3] <= rh || g[3] >= 2 * rh) {
+    e->err |= ERR_BAD_RESPAWN; g[0] = 1; g[1] = 1; g[2] = rw + 1; g[3] = rh + 1;
+  }
+  const int gx[4] = {rw, g[1], g[2], rw}, gy[4] = {g[0], rh, rh, g[3]};
+  /* the loop of :68-90, in its order: (j=0,i=0) vertical top + gap, horizontal left + gap; (j=0,i=1) horizontal
+   * right + gap; (j=1,i=0) vertical bottom + gap */
+  for (int step = 0; step < 4; ++step) {
+    if (step == 0) for (int y = 0; y < rh; ++y) grid_set(&e->grid, rw, y, wall);            /* vert_wall(x_right, y_top, room_h) */
+    if (step == 1) for (int x = 0; x < rw; ++x) grid_set(&e->grid, x, rh, wall);            /* horz_wall(x_left, y_bottom, room_w) */
+    if (step == 2) for (int x = rw; x < 2 * rw; ++x) grid_set(&e->grid, x, rh, wall);
+    if (step == 3) for (int y = rh; y < 2 * rh; ++y) grid_set(&e->grid, rw, y, wall);
+    if (!(gx[step] <= 1 || gx[step] >= W - 1 || gy[step] <= 0 || gy[step] >= H - 1)) grid_set(&e->grid, gx[step], gy[step], NONE);
+  }
+  e->last_scatter[0] = (int8_t)g[0]; e->last_scatter[1] = (int8_t)g[1];
+  e->last_scatter[2] = (int8_t)g[2]; e->last_scatter[3] = (int8_t)g[3];
+  e->spawn_w = W;
+  for (int a = 0; a < e->A; ++a) place_one_agent(e, a);                                      /* place_agent() :98 */
+  int8_t rec[4], inj[4] = {0, 0, 0, 0};
+  if (e->inj_scatter) { inj[0] = e->inj_scatter[4]; inj[1] = e->inj_scatter[5]; }
+  place_object(e, goal, P_GEN, 1, W, e->inj_scatter ? inj : NULL, rec);                      /* place_obj(Goal()) :104 */
+  e->last_scatter[4] = rec[0]; e->last_scatter[5] = rec[1];
+  e->n_scatter = 3;
+}
+
 static void do_reset(mgo_env* e, const int8_t* spawn, uint64_t t) {
   for (int a = 0; a < e->A; ++a) { e->has_pos[a] = 0; e->done[a] = 0; }   /* multigrid.py:471-473 */
   e->inj = spawn; e->purpose = P_SPAWN; e->t = t;
   if (e->kind == KIND_DOORKEY) gen_doorkey(e);
   else if (e->kind == KIND_CLUTTERED || e->kind == KIND_MEETUP) gen_scatter(e);
+  else if (e->kind == KIND_FOURROOMS) gen_fourrooms(e);
   else {
     e->grid = e->base;                                   /* _gen_grid with the fixed seed */
     for (int a = 0; a < e->A; ++a) place_one_agent(e, a); /* cluttered.py:61-63 */
@@ -792,7 +838,7 @@ void mgo_aux_words(const mgo_env* e, uint32_t* out /* [4] */) {
     for (int i = 0; i < e->n_goals; ++i) out[i] = (uint32_t)e->goal_x[i] | ((uint32_t)e->goal_y[i] << 6);
     for (int a = 0; a < e->A && a < 4; ++a) out[3] |= (uint32_t)e->past_dist[a] << (8 * a);
   }
-  if (e->kind == KIND_CLUTTERED && e->n_goals) {        /* the scattered goal, which the v8 shaper measures to */
+  if ((e->kind == KIND_CLUTTERED && e->n_goals) || e->kind == KIND_FOURROOMS) {   /* the scattered goal, which the v8 shaper measures to */
     int gx, gy;
     goal_position(e, &gx, &gy);
     out[0] = (uint32_t)gx | ((uint32_t)gy << 6);

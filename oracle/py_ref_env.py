@@ -571,6 +571,38 @@ class PyMeetupEnv(PyClutteredEnv):
             'position': list(self.agent_pos)}
 
 
+class PyFourRoomsEnv(PyClutteredEnv):
+  """FourRoomsEnv with two_rooms=False and no fixed agent / goal positions (multigrid_envs/fourrooms.py:25-107)."""
+
+  def __init__(self, grid_size=19, n_agents=3, view_size=7, **kw):
+    super().__init__(size=grid_size, n_agents=n_agents, n_clutter=0, view_size=view_size, max_steps=100, **kw)
+
+  def _gen_grid(self):
+    w = h = self.size
+    self._wall_rect()                                                    # fourrooms.py:58-61
+    room_w, room_h = w // 2, h // 2
+
+    def carve(pos):                                                      # :78-80, 87-89
+      if not (pos[0] <= 1 or pos[0] >= w - 1 or pos[1] <= 0 or pos[1] >= h - 1):
+        self.grid.set(pos[0], pos[1], None)
+
+    for j in range(2):                                                   # :66-90
+      for i in range(2):
+        x_left, y_top = i * room_w, j * room_h
+        x_right, y_bottom = x_left + room_w, y_top + room_h
+        if i + 1 < 2:
+          for y in range(y_top, y_top + room_h):
+            self.grid.set(x_right, y, Wall())
+          carve((x_right, self.rand_int(y_top + 1, y_bottom)))
+        if j + 1 < 2:
+          for x in range(x_left, x_left + room_w):
+            self.grid.set(x, y_bottom, Wall())
+          carve((self.rand_int(x_left + 1, x_right), y_bottom))
+    for a in range(self.n_agents):                                       # place_agent() :98
+      self.place_one_agent(a)
+    self.place_obj(Goal())                                               # :104
+
+
 class V8Shaper:
   """v8_robust_ppo.py:126-129, 159-220, 227-229."""
 

@@ -100,6 +100,38 @@ def test_cluttered_random_layout_parity(size, A, V, rand_goal, clutter, lava, n,
   env.close()
 
 
+@pytest.mark.parametrize('size,A,V,n,steps', [(15, 3, 5, 2000, 210), (19, 1, 7, 500, 120), (6, 1, 5, 1500, 210), (8, 2, 7, 800, 150)])
+def test_fourrooms_parity(size, A, V, n, steps):
+  """FourRooms: wall gaps, agents and goal drawn per env and per reset; the v8 shaper measures to the env's own goal."""
+  _need_gpu()
+  env, orc = _make('fourrooms', size, A, n, 100, seed=size + A, V=V, n_goals=0, n_clutter=0)
+  env.reset()
+  orc.reset()
+  _cmp(env, orc, 'reset', step=False)
+  touches = 0
+  for t in range(steps):
+    env.step_random()
+    orc.step()
+    _cmp(env, orc, 'step %d' % t)
+    touches += int((orc.env_reward[:, :n] > 0).sum())
+  assert env.check_errors() == 0 and orc.errors() == 0
+  if size <= 8:
+    assert touches > 0
+  # injection of recorded gaps / goal / spawns under another device seed
+  env2, _ = _make('fourrooms', size, A, n, 100, seed=999, V=V, n_goals=0, n_clutter=0)
+  _, scatter = orc.aux_state()
+  orc.reset()
+  _, scatter = orc.aux_state()
+  _, _, spawn = orc.last_draws()
+  env2.reset(spawn=spawn, scatter=scatter)
+  assert env2.check_errors() == 0
+  _, kinds = orc.dyn_state()
+  assert np.array_equal(env2.grid_kinds().cpu().numpy(), kinds[:n])
+  assert np.array_equal(env2.agent_state.cpu().numpy().view(np.uint32), orc.agent_state()[:, :n])
+  assert np.array_equal(env2.obs_image.cpu().numpy().reshape(A, n, -1), orc.obs_image[:, :n])
+  env.close(); env2.close()
+
+
 def test_scatter_injection_and_errors():
   """The recorded layout draws of an oracle run injected into a device run keyed with another seed."""
   _need_gpu()
@@ -140,6 +172,21 @@ def test_scatter_registry_ids():
   assert np.array_equal(env.obs_full.cpu().numpy().reshape(64, -1), orc.obs_image[0, :64])
   o = env.obs()
   assert len(o['image']) == 3 and o['position'].shape == (3, 64, 2)
+  env.close()
+  env = multigrid_amd.make_batched('MultiGrid-FourRooms-15x15-v0', 128, seed=4)
+  orc = c_oracle.OracleBatch(None, 128, W=15, H=15, A=3, V=5, max_steps=100, shaping=1, auto_reset=1, seed=4, kind='fourrooms')
+  env.reset(); orc.reset()
+  for _ in range(10):
+    env.step_random(); orc.step()
+  assert np.array_equal(env.obs_image.cpu().numpy().reshape(3, 128, -1), orc.obs_image[:, :128])
+  env.close()
+  env = multigrid_amd.make_batched('MultiGrid-Empty-Random-8x8-v0', 128, seed=4)
+  orc = c_oracle.OracleBatch(env.cells, 128, W=8, H=8, A=3, V=5, max_steps=128, see_through=1, shaping=1, auto_reset=1, seed=4)
+  env.reset(); orc.reset()
+  for _ in range(140):
+    env.step_random(); orc.step()
+  assert np.array_equal(env.obs_image.cpu().numpy().reshape(3, 128, -1), orc.obs_image[:, :128])
+  assert np.array_equal(env.reward.cpu().numpy().view(np.int64), orc.reward[:, :128].view(np.int64))
   env.close()
   env = multigrid_amd.make('MultiGrid-Cluttered-v0', shaping=None, auto_reset=False, seed=9)
   obs = env.reset()

@@ -110,6 +110,72 @@ def _cross(kind, size, A, steps, seed, max_steps, **gen):
   return ev
 
 
+def test_fourrooms_known_layout():
+  """15x15 with gaps injected: walls at x = 7 and y = 7, the four gaps, and the quirk that a gap at x <= 1 is not carved."""
+  env = c_oracle.OracleEnv(None, W=15, H=15, A=3, V=5, max_steps=100, kind='fourrooms')
+  env.reset(spawn=[(1, 1, 0), (2, 1, 0), (3, 1, 0)], scatter=[(3, 1), (10, 12), (13, 13)])
+  assert env.errors() == 0
+  g = env.grid()
+  wall, empty = (2, 5, 0), (1, 0, 0)
+  for k in range(1, 14):
+    want_v = empty if k in (3, 12) else wall          # vertical wall x = 7: gaps at y = 3 (top) and y = 12 (bottom)
+    assert tuple(g[k, 7]) == want_v, k
+    want_h = empty if k == 10 else wall               # horizontal wall y = 7: right gap at x = 10; the left gap x = 1 is NOT carved
+    assert tuple(g[7, k]) == want_h, k
+  assert tuple(g[13, 13]) == (8, 1, 0)
+  assert int((g[:, :, 0] == 2).sum()) == 56 + 13 + 13 - 1 - 3     # border + two walls (sharing (7,7)) - three gaps
+  assert env.aux_words()[0] == 13 | 13 << 6
+
+
+def _cross_fourrooms(size, A, V, steps, seed):
+  rng = np.random.default_rng(seed)
+  c = c_oracle.OracleEnv(None, W=size, H=size, A=A, V=V, max_steps=100, kind='fourrooms', seed=seed, gid=seed + 5)
+  feed = Feed()
+
+  def after_reset():
+    sc = c.last_scatter()
+    _, _, spawn = c.last_draws()
+    q = [int(sc[0][0]), int(sc[0][1]), int(sc[1][0]), int(sc[1][1])]     # draw order: top, left, right, bottom
+    for s_ in spawn:
+      q += [int(s_[0]), int(s_[1]), int(s_[2])]
+    return q + [int(sc[2][0]), int(sc[2][1])]
+
+  c.reset()
+  feed.q = after_reset()
+  py = py_ref_env.PyFourRoomsEnv(grid_size=size, n_agents=A, view_size=V, rand_int=feed.rand_int, order_fn=lambda: feed.order)
+  assert not feed.q
+  episodes = touches = 0
+  for t in range(steps):
+    assert np.array_equal(c.grid(), py_grid(py)), t
+    acts = [int(v) for v in rng.choice(7, size=A, p=[.15, .15, .4, .075, .075, .075, .075])]
+    obs, rew, done, _ = c.step(acts)
+    order, respawn, _ = c.last_draws()
+    _, objdrop = c.last_gen()
+    feed.order = [int(o) for o in order]
+    feed.q = step_queue(feed.order, respawn, objdrop)
+    pobs, prew, pdone, _ = py.step(acts)
+    assert not feed.q and [float(r) for r in prew] == list(c.env_rewards) and bool(pdone) == done
+    for a in range(A):
+      assert np.array_equal(obs['image'][a], pobs['image'][a]), (t, a)
+    touches += sum(1 for r in c.env_rewards if r > 0)
+    if done:
+      episodes += 1
+      c.reset()
+      feed.q = after_reset()
+      py.reset()
+      assert not feed.q
+  return episodes, touches
+
+
+def test_fourrooms_cross():
+  ep, touches = _cross_fourrooms(15, 3, 5, 1500, seed=3)
+  assert ep >= 14
+  ep, touches = _cross_fourrooms(6, 1, 5, 2500, seed=4)
+  assert ep > 30 and touches > 0
+  ep, _ = _cross_fourrooms(19, 1, 7, 400, seed=5)
+  assert ep >= 3
+
+
 def test_meetup_cross_6x6():
   ev = _cross('meetup', 6, 3, 3000, seed=2, max_steps=60, n_goals=3, n_clutter=0)
   assert ev['episodes'] > 20 and ev['reward'] > 200 and ev['early'] > 0, ev
