@@ -603,7 +603,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 }
 
 template <int A, int V>
-__global__ __launch_bounds__(256) void mg_dyn_kernel(const Params p) {
+__global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up to 8 waves per workgroup (dyn_geometry)
   constexpr int ROWB = ViewGeom<V>::ROWB;
   extern __shared__ __align__(16) uint8_t smem[];
   // LDS carve: [stage: nw x 64*ROWB B][grids: nw x (W+2)(H+2)*68 B][distance LUT: LW*LH f64][kind LUT: 256 u32]

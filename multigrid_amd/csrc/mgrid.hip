@@ -822,6 +822,7 @@ struct mg_handle {
   uint32_t* aux;
   uint8_t* obs_full;
   bool full_obs;
+  int dyn_waves_cu;      // waves of the mutable-grid kernel a CU can hold by registers
   int LW, LH;            // dims of the mutable-grid kernel's relative distance LUT
   mg_buffers buf;
   std::vector<void*> allocs;
@@ -884,11 +885,22 @@ void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* l
   const size_t rowb = h->full_obs ? 0 : (size_t)c.view_size * c.view_size * 3;   // fully observed images are not staged
   const size_t fixed = ((size_t)h->LW * h->LH * 8 + (size_t)c.width * c.height * 4 + 256 * 4 + (size_t)h->GW * 4 + 8 + 15) / 16 * 16;
   const size_t per_wave = (size_t)kWave * rowb + (size_t)(c.width + 2) * (c.height + 2) * kCellB;
-  int nw = 4;
-  while (nw > 1 && (fixed + nw * per_wave > (size_t)kLdsLimit || h->n_chunks < (int64_t)h->n_cu * nw)) nw >>= 1;
+  // waves per workgroup (1..8) that keep the most waves resident per CU: at most dyn_waves_cu by registers
+  // (queried from the code object at mg_create: 512 VGPRs per SIMD lane / the kernel's count, x 4 SIMDs), and
+  // whatever fits 160 KB of LDS.  Ties go to the smaller workgroup; small batches shrink it further so that
+  // every CU gets work.
+  const int kDynWavesPerCU = h->dyn_waves_cu;
+  int nw = 1, best = 0;
+  for (int cand = 1; cand <= 8; ++cand) {
+    const size_t need = fixed + cand * per_wave;
+    if (need > (size_t)kLdsLimit) break;
+    const int resident = std::min(kDynWavesPerCU, cand * (int)((size_t)kLdsLimit / need));
+    if (resident > best) { best = resident; nw = cand; }
+  }
+  while (nw > 1 && h->n_chunks < (int64_t)h->n_cu * nw) nw >>= 1;
   const size_t lds = fixed + nw * per_wave;
   int per_cu = (int)((size_t)kLdsLimit / lds);
-  per_cu = std::max(1, std::min(per_cu, 32 / nw));
+  per_cu = std::max(1, std::min(per_cu, kDynWavesPerCU / nw));
   const int64_t blocks = (h->n_chunks + nw - 1) / nw;
   *nw_out = nw;
   *grid_out = (unsigned)std::min<int64_t>(blocks, (int64_t)h->n_cu * per_cu);
@@ -1040,6 +1052,14 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   h->dynamic = false; h->dvar = dvar; h->GW = (c.width * c.height + 3) / 4;
   h->base_grid = nullptr; h->carry = nullptr; h->grid = nullptr; h->aux = nullptr; h->obs_full = nullptr;
   h->full_obs = c.env_kind == MG_KIND_MEETUP; h->LW = c.width; h->LH = c.height;
+  h->dyn_waves_cu = 8;
+  if (dvar) {
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(dvar->fn)) == hipSuccess && fa.numRegs > 0) {
+      const int regs = (fa.numRegs + 7) / 8 * 8;                  // gfx950: 512 VGPRs per SIMD lane, allocated in 8s
+      h->dyn_waves_cu = 4 * std::max(1, std::min(8, 512 / regs));
+    }
+  }
   h->use_table = false; h->n_entries = 0; h->view_table = nullptr; h->cell_index = nullptr;
   h->stride = (c.n_envs + 63) / 64 * 64;
   h->n_chunks = h->stride / 64;
