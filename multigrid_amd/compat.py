@@ -52,6 +52,16 @@ class _LiveGridView:
     return None if k == 0 else _Cell(k)
 
 
+class Box:
+  """Stand-in for gym.spaces.Box metadata (multigrid.py:396-440); gym is not a dependency of this package."""
+
+  def __init__(self, low, high, shape, dtype):
+    self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+  def __repr__(self):
+    return 'Box(%r, %r, %r, %s)' % (self.low, self.high, self.shape, self.dtype)
+
+
 class RefCompatEnv:
   """One env (N = 1) with the reference's list-of-arrays contract; rewards are the unshaped env
   rewards unless the batched env was built with shaping='v8'."""
@@ -64,6 +74,13 @@ class RefCompatEnv:
     self.max_steps = batched.max_steps
     self.agent_view_size = batched.view_size
     self.grid = _LiveGridView(batched) if batched.mutable_grid else _GridView(batched.cells)
+    A, V = self.n_agents, batched.view_size
+    img_shape = (A, batched.width, batched.height, 3) if batched.obs_full is not None else (A, V, V, 3)
+    self.action_space = Box(0, 6, (A,), 'int64')                                   # multigrid.py:396-400
+    self.observation_space = {'image': Box(0, 255, img_shape, 'uint8'),            # multigrid.py:402-440
+                              'direction': Box(0, 3, (A,), 'uint8')}
+    if batched.obs_full is not None:
+      self.observation_space['position'] = Box(0, max(batched.width, batched.height), (A, 2), 'uint8')
 
   def _obs(self):
     d = self.b.obs_dir[:, 0].cpu().numpy()

@@ -114,6 +114,43 @@ def ppo_loss(model, images, directions, actions, old_log_probs, advantages, retu
   return policy_loss + value_loss + entropy_loss
 
 
+class EpisodeStats:
+  """run_episode's bookkeeping (v8_robust_ppo.py:233-271) for N envs at once, on device: per-agent return of the
+  episode in progress, goal touches (shaped reward >= 4.5, v8:246-248), and sums over finished episodes.
+  `reduce()` adds the finished-episode sums over all ranks (one small all-reduce: RCCL on GPUs, gloo in tests)."""
+
+  def __init__(self, n_agents, n_envs, device):
+    self.ep_return = torch.zeros((n_agents, n_envs), dtype=torch.float64, device=device)
+    self.ep_touches = torch.zeros(n_envs, dtype=torch.int64, device=device)
+    # finished episodes: [count, sum of collective returns, sum of goal touches]
+    self.totals = torch.zeros(3, dtype=torch.float64, device=device)
+
+  @torch.no_grad()
+  def add(self, reward, done):
+    """reward [A, N] (or [T, A, N]), done [N] (or [T, N]) of one step (or T steps in order)."""
+    if reward.dim() == 3:
+      for t in range(reward.shape[0]):
+        self.add(reward[t], done[t])
+      return
+    self.ep_return += reward.to(torch.float64)
+    self.ep_touches += (reward >= 4.5).sum(dim=0)
+    fin = done.bool()
+    self.totals[0] += fin.sum()
+    self.totals[1] += self.ep_return.sum(dim=0)[fin].sum()       # collective reward = sum over agents (v8:425)
+    self.totals[2] += self.ep_touches[fin].sum()
+    self.ep_return[:, fin] = 0
+    self.ep_touches[fin] = 0
+
+  def reduce(self):
+    """{'episodes', 'mean_collective_return', 'goal_touches'} over every rank's finished episodes."""
+    import torch.distributed as dist
+    t = self.totals.clone()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+      dist.all_reduce(t)
+    n = float(t[0])
+    return {'episodes': int(n), 'mean_collective_return': float(t[1]) / n if n else 0.0, 'goal_touches': int(t[2])}
+
+
 class BatchedController:
   """SimpleController (v8_robust_ppo.py:105-366) over N envs at once.
 
@@ -141,6 +178,19 @@ class BatchedController:
     else:
       self.models = self.nets
     self.optimizers = [torch.optim.Adam(n.parameters(), lr=lr) for n in self.nets]
+    self.stats = EpisodeStats(self.n_agents, env.n_envs, self.device)
+
+  def save_models(self, path_prefix):
+    """save_models (v8_robust_ppo.py:362-366): one state_dict per agent, the reference's file names."""
+    import os
+    os.makedirs(os.path.dirname(path_prefix) or '.', exist_ok=True)
+    for i, net in enumerate(self.nets):
+      torch.save(net.state_dict(), '%s_agent_%d.pth' % (path_prefix, i))
+
+  def load_models(self, path_prefix):
+    """Loads files written by save_models — or by the reference: the module names are the same."""
+    for i, net in enumerate(self.nets):
+      net.load_state_dict(torch.load('%s_agent_%d.pth' % (path_prefix, i), map_location=self.device, weights_only=True))
 
   @torch.no_grad()
   def rollout(self, n_steps, use_graph=None):

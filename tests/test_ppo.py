@@ -144,19 +144,31 @@ def _ddp_worker(rank, world, port, out_dir):
   ctl = P.BatchedController(env, device=torch.device('cpu'), seed=5)
   assert ctl.ddp
   torch.manual_seed(100 + rank)                             # different action samples per rank
-  ctl.update(ctl.rollout(40))
+  traj = ctl.rollout(40)
+  ctl.update(traj)
   torch.save([p.detach() for p in ctl.nets[1].parameters()], os.path.join(out_dir, 'p%d.pt' % rank))
+  # episode statistics: every rank's own sums, then the all-reduced total must be the same on both
+  ctl.stats.add(torch.stack(traj['reward'], dim=1), traj['done'])
+  local = ctl.stats.totals.clone()
+  red = ctl.stats.reduce()
+  torch.save({'local': local, 'reduced': red}, os.path.join(out_dir, 's%d.pt' % rank))
   dist.barrier()
   dist.destroy_process_group()
 
 
 def test_ddp_gradient_allreduce_keeps_ranks_in_lockstep(tmp_path):
+  """(also: EpisodeStats.reduce() sums the ranks' finished-episode totals)"""
   import torch.multiprocessing as mp
   port = 29700 + (os.getpid() % 1500)
   mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
   p0 = torch.load(os.path.join(str(tmp_path), 'p0.pt'), weights_only=True)
   p1 = torch.load(os.path.join(str(tmp_path), 'p1.pt'), weights_only=True)
   assert all(torch.equal(a, b) for a, b in zip(p0, p1))     # same weights after 4 all-reduced epochs
+  s0 = torch.load(os.path.join(str(tmp_path), 's0.pt'), weights_only=True)
+  s1 = torch.load(os.path.join(str(tmp_path), 's1.pt'), weights_only=True)
+  assert s0['reduced'] == s1['reduced']
+  assert s0['reduced']['episodes'] == int(s0['local'][0] + s1['local'][0])
+  assert s0['reduced']['goal_touches'] == int(s0['local'][2] + s1['local'][2])
 
 
 def test_multigrid_net_matches_reference_layout():
@@ -201,6 +213,45 @@ def test_gpu_rollout_update_on_device_env():
   env2 = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', 2048, seed=1)
   env2.reset()
   assert torch.equal(traj['image'][1][0], env2.obs_image[1])
+
+
+def test_episode_stats_match_a_per_env_loop():
+  """EpisodeStats against the reference's per-episode bookkeeping (v8_robust_ppo.py:233-271, 425) done env by env."""
+  import torch
+  rng = np.random.RandomState(0)
+  A, N, T = 3, 37, 120
+  reward = rng.choice([0.0, 0.03, -0.05, 5.0], size=(T, A, N), p=[.5, .3, .15, .05])
+  done = rng.rand(T, N) < 0.04
+  st = ppo.EpisodeStats(A, N, torch.device('cpu'))
+  st.add(torch.from_numpy(reward), torch.from_numpy(done))
+  episodes, total, touches = 0, 0.0, 0
+  for n in range(N):
+    ep, tc = np.zeros(A), 0
+    for t in range(T):
+      ep += reward[t, :, n]
+      tc += int((reward[t, :, n] >= 4.5).sum())
+      if done[t, n]:
+        episodes += 1; total += ep.sum(); touches += tc
+        ep, tc = np.zeros(A), 0
+  out = st.reduce()
+  assert out['episodes'] == episodes and out['goal_touches'] == touches
+  assert abs(out['mean_collective_return'] - total / episodes) < 1e-9
+
+
+def test_save_and_load_models_round_trip(tmp_path):
+  import torch
+
+  class FakeEnv:
+    n_agents, n_envs = 2, 4
+    obs_image = torch.zeros((2, 4, 5, 5, 3), dtype=torch.uint8)
+  a = ppo.BatchedController(FakeEnv(), ddp=False, seed=1)
+  b = ppo.BatchedController(FakeEnv(), ddp=False, seed=2)
+  a.save_models(str(tmp_path / 'm' / 'best'))
+  assert (tmp_path / 'm' / 'best_agent_1.pth').exists()
+  b.load_models(str(tmp_path / 'm' / 'best'))
+  for x, y in zip(a.nets, b.nets):
+    for p, q in zip(x.parameters(), y.parameters()):
+      assert torch.equal(p, q)
 
 
 @pytest.mark.gpu
