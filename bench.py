@@ -90,6 +90,12 @@ def main():
                   '(mutable-grid kernel: DoorKey / Meetup / random Cluttered), not the BASELINE metric')
   args = ap.parse_args()
 
+  # stdout carries exactly one line, the JSON: library banners (RCCL prints its version block to stdout when the
+  # first communicator is created, gloo its peer count) are sent to stderr by pointing fd 1 there until the end
+  sys.stdout.flush()
+  real_stdout = os.dup(1)
+  os.dup2(2, 1)
+
   import torch
   import multigrid_amd
   from multigrid_amd import shard
@@ -172,7 +178,10 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline and headline:
       out['cpu_baseline'] = cpu_baseline(env.cells, args.cpu_seconds)
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
   env.close()
   if dist is not None:
     dist.destroy_process_group()
