@@ -64,7 +64,10 @@ __host__ __device__ inline uint32_t kind_word(uint32_t k) {
 // at byte ((y+1)*(W+2) + x+1)*kCellB + l.  gl = the wave's grid base + lane.
 constexpr int kCellB = 68;    // bytes per cell row: 64 lanes + 4 (bank spreading)
 constexpr int kCellW = 17;    // the same in dwords
-constexpr int kPreMax = 16;   // grid dwords per lane that are prefetched in registers (W*H <= 64)
+constexpr int kPreMax = 16;   // grid dwords per lane fetched per batch when a grid is not prefetched
+// PRE (template parameter of the kernels) = grid dwords per lane prefetched in registers: 16 covers grids up to 64
+// cells; the view-5 and the fully observed instantiations also exist with 64 (grids up to 16x16 — they have the
+// registers for it at two waves per SIMD), picked at mg_create for grids that need it.
 __device__ __forceinline__ int g_off(const Params& p, int x, int y) { return ((y + 1) * (p.W + 2) + x + 1) * kCellB; }
 __device__ __forceinline__ uint32_t g_get(const uint8_t* gl, int off) { return gl[off]; }
 __device__ __forceinline__ void g_set(uint8_t* gl, int off, uint32_t k) { gl[off] = (uint8_t)k; }
@@ -152,16 +155,16 @@ __device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, cons
 
 // Inputs of one chunk, requested one chunk ahead with inline-asm loads and retired with a counted
 // s_waitcnt (see load_chunk / wait_chunk in mgrid.hip for why).
-template <int A>
+template <int A, int PRE>
 struct DynIn {
   uint32_t st[4];           // env_state words (A + 1 used)
   uint32_t carry, act;
   uint32_t aux[4];          // MEETUP: goal positions and past distances
-  uint32_t pre[kPreMax];    // this lane's share of the chunk's grid rows (dword lane + 64k), GW <= kPreMax only
+  uint32_t pre[PRE];        // this lane's share of the chunk's grid rows (dword lane + 64k), GW <= PRE only
 };
 
-template <int A>
-__device__ __forceinline__ void dyn_load(const Params& p, int64_t env0, int lane, DynIn<A>& in) {
+template <int A, int PRE>
+__device__ __forceinline__ void dyn_load(const Params& p, int64_t env0, int lane, DynIn<A, PRE>& in) {
   const int64_t n = env0 + lane;
 #pragma unroll
   for (int a = 0; a < 4; ++a) in.st[a] = 0u;
@@ -177,23 +180,30 @@ __device__ __forceinline__ void dyn_load(const Params& p, int64_t env0, int lane
   }
   const uint32_t* ghbm = p.grid + (env0 >> 6) * (int64_t)p.GW * kWave + lane;
 #pragma unroll
-  for (int k = 0; k < kPreMax; ++k) {
+  for (int k = 0; k < PRE; ++k) {
     in.pre[k] = 0u;
-    if (k < p.GW && p.GW <= kPreMax) in.pre[k] = asm_load_u32(ghbm + k * kWave);
+    if (k < p.GW && p.GW <= PRE) in.pre[k] = asm_load_u32(ghbm + k * kWave);
   }
 }
 
-template <int A, int K>
-__device__ __forceinline__ void dyn_wait(DynIn<A>& in) {
-  static_assert(A <= 3 && kPreMax == 16, "operand list below");
-  asm volatile("s_waitcnt vmcnt(%26)"
+template <int A, int K, int PRE>
+__device__ __forceinline__ void dyn_wait(DynIn<A, PRE>& in) {
+  static_assert(A <= 3 && PRE % 16 == 0, "operand lists below");
+  asm volatile("s_waitcnt vmcnt(%10)"
                : "+v"(in.st[0]), "+v"(in.st[1]), "+v"(in.st[2]), "+v"(in.st[3]),
-                 "+v"(in.carry), "+v"(in.act), "+v"(in.aux[0]), "+v"(in.aux[1]), "+v"(in.aux[2]), "+v"(in.aux[3]),
-                 "+v"(in.pre[0]), "+v"(in.pre[1]), "+v"(in.pre[2]), "+v"(in.pre[3]), "+v"(in.pre[4]), "+v"(in.pre[5]),
-                 "+v"(in.pre[6]), "+v"(in.pre[7]), "+v"(in.pre[8]), "+v"(in.pre[9]), "+v"(in.pre[10]), "+v"(in.pre[11]),
-                 "+v"(in.pre[12]), "+v"(in.pre[13]), "+v"(in.pre[14]), "+v"(in.pre[15])
+                 "+v"(in.carry), "+v"(in.act), "+v"(in.aux[0]), "+v"(in.aux[1]), "+v"(in.aux[2]), "+v"(in.aux[3])
                : "n"(K)
                : "memory");
+  // the grid rows: volatile asm statements keep their order, so no use of these registers can move above the wait
+#pragma unroll
+  for (int k = 0; k < PRE; k += 16)
+    asm volatile(""
+                 : "+v"(in.pre[k]), "+v"(in.pre[k + 1]), "+v"(in.pre[k + 2]), "+v"(in.pre[k + 3]), "+v"(in.pre[k + 4]),
+                   "+v"(in.pre[k + 5]), "+v"(in.pre[k + 6]), "+v"(in.pre[k + 7]), "+v"(in.pre[k + 8]), "+v"(in.pre[k + 9]),
+                   "+v"(in.pre[k + 10]), "+v"(in.pre[k + 11]), "+v"(in.pre[k + 12]), "+v"(in.pre[k + 13]),
+                   "+v"(in.pre[k + 14]), "+v"(in.pre[k + 15])
+                 :
+                 : "memory");
 }
 
 // MeetupEnv.get_dist (meetup.py:78-84): Manhattan distance of every agent to the goal whose summed
@@ -282,10 +292,10 @@ __device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uin
 }
 
 // One chunk (64 envs) of one step()/reset() on mutable grids.
-template <int A, int V>
+template <int A, int V, bool FULL, int PRE>
 __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, const uint32_t* lut, const uint32_t* base,
                                           const uint16_t* pidx, const uint16_t* cpc, uint32_t* stage, uint32_t* gw, int lane,
-                                          int64_t env0, const DynIn<A>& in, uint32_t& err_acc) {
+                                          int64_t env0, const DynIn<A, PRE>& in, uint32_t& err_acc) {
   constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
   const int64_t n = env0 + lane;
   const bool active = n < p.n_envs;
@@ -297,14 +307,14 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   //      lanes 4*(d%16)..+3 of cell d/16; it goes to LDS dword pidx[cell]*17 + d%16. ---------------
   uint32_t* const ghbm = p.grid + (env0 >> 6) * (int64_t)p.GW * kWave;
   const int l4 = lane & 15, c4 = lane >> 4;
-  if (p.GW <= kPreMax) {
+  if (p.GW <= PRE) {
 #pragma unroll
-    for (int k = 0; k < kPreMax; ++k) {
+    for (int k = 0; k < PRE; ++k) {
       const int ci = c4 + 4 * k;
       if (k < p.GW && ci < cells) gw[(int)pidx[ci] * kCellW + l4] = in.pre[k];
     }
   } else {
-    // larger grids: rows fetched kPreMax at a time (all loads of a batch in flight together)
+    // grids beyond the prefetch registers: rows fetched kPreMax at a time (all loads of a batch in flight together)
     for (int k0 = 0; k0 < p.GW; k0 += kPreMax) {
       uint32_t row[kPreMax];
 #pragma unroll
@@ -588,7 +598,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 
   // ---- gen_obs (multigrid.py:1037-1067) --------------------------------------------------------
 #if MG_ABL != 2
-  if (p.full_obs) {
+  if (FULL) {
     emit_full<A>(p, g, reinterpret_cast<const uint8_t*>(gw), lut, cpc, pd, lane, p.obs_full + env0 * (int64_t)(p.W * p.H * 3));
   } else {
 #pragma unroll
@@ -602,7 +612,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 #endif
 }
 
-template <int A, int V>
+template <int A, int V, bool FULL, int PRE>
 __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up to 8 waves per workgroup (dyn_geometry)
   constexpr int ROWB = ViewGeom<V>::ROWB;
   extern __shared__ __align__(16) uint8_t smem[];
@@ -611,7 +621,7 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up t
   const int nw = blockDim.x >> 6;
   const int pcells = (p.W + 2) * (p.H + 2), cells = p.W * p.H;
   uint32_t* stage_all = reinterpret_cast<uint32_t*>(smem);
-  const int stage_b = p.full_obs ? 0 : kWave * ROWB;    // per wave; fully observed images are gathered without staging
+  const int stage_b = FULL ? 0 : kWave * ROWB;    // per wave; fully observed images are gathered without staging
   uint32_t* grids = reinterpret_cast<uint32_t*>(smem + (size_t)nw * stage_b);
   double* dist = reinterpret_cast<double*>(grids + (size_t)nw * pcells * kCellW + ((nw * pcells * kCellW) & 1));
   uint32_t* lut = reinterpret_cast<uint32_t*>(dist + p.LW * p.LH);
@@ -624,8 +634,8 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up t
   // before the LDS tables are filled
   const int64_t cstride = (int64_t)gridDim.x * nw;
   int64_t c = (int64_t)blockIdx.x * nw + wv;
-  DynIn<A> cur, nxt;
-  if (c < p.n_chunks) dyn_load<A>(p, c * kWave, lane, cur);
+  DynIn<A, PRE> cur, nxt;
+  if (c < p.n_chunks) dyn_load<A, PRE>(p, c * kWave, lane, cur);
 
   for (int i = tid; i < 256; i += blockDim.x) lut[i] = kind_word((uint32_t)i);
   for (int i = tid; i < p.GW; i += blockDim.x) base[i] = p.base_grid[i];
@@ -650,14 +660,14 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up t
 #endif
   constexpr int kLo = (kObs + A + 3) < 63 ? (kObs + A + 3) : 63;   // the grid rows go back only when a lane changed its grid
   constexpr int kFull = A + 3;                                     // fully observed: at least these
-  if (c < p.n_chunks) dyn_wait<A, 0>(cur);
+  if (c < p.n_chunks) dyn_wait<A, 0, PRE>(cur);
   for (; c < p.n_chunks; c += cstride) {
     const int64_t cn = c + cstride;
     const bool more = cn < p.n_chunks;          // wave-uniform
-    if (more) dyn_load<A>(p, cn * kWave, lane, nxt);
-    dyn_chunk<A, V>(p, dist, lut, base, pidx, cpc, stage, gw, lane, c * kWave, cur, err);
+    if (more) dyn_load<A, PRE>(p, cn * kWave, lane, nxt);
+    dyn_chunk<A, V, FULL, PRE>(p, dist, lut, base, pidx, cpc, stage, gw, lane, c * kWave, cur, err);
     if (more) {
-      if (p.full_obs) dyn_wait<A, kFull>(nxt); else dyn_wait<A, kLo>(nxt);
+      if (FULL) dyn_wait<A, kFull, PRE>(nxt); else dyn_wait<A, kLo, PRE>(nxt);
       cur = nxt;
     }
   }

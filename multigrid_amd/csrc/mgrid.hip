@@ -735,10 +735,15 @@ const Variant kVariants[] = {
 };
 
 // mutable-grid kernel instantiations
-struct DynVariant { int A, V; kernel_fn fn; };
+struct DynVariant { int A, V; bool full; int pre; kernel_fn fn; };
+#define MG_DYN(A, V, FULL, PRE) {A, FULL ? 0 : V, FULL, PRE, mg_dyn_kernel<A, V, FULL, PRE>}
 const DynVariant kDynVariants[] = {
-    {1, 7, mg_dyn_kernel<1, 7>}, {2, 7, mg_dyn_kernel<2, 7>}, {3, 7, mg_dyn_kernel<3, 7>},
-    {1, 5, mg_dyn_kernel<1, 5>}, {2, 5, mg_dyn_kernel<2, 5>}, {3, 5, mg_dyn_kernel<3, 5>},
+    MG_DYN(1, 7, false, 16), MG_DYN(2, 7, false, 16), MG_DYN(3, 7, false, 16),
+    MG_DYN(1, 5, false, 16), MG_DYN(2, 5, false, 16), MG_DYN(3, 5, false, 16),
+    MG_DYN(1, 5, false, 64), MG_DYN(2, 5, false, 64), MG_DYN(3, 5, false, 64),
+    // fully observed kinds (no views; the V parameter is unused)
+    MG_DYN(1, 5, true, 16), MG_DYN(2, 5, true, 16), MG_DYN(3, 5, true, 16),
+    MG_DYN(1, 5, true, 64), MG_DYN(2, 5, true, 64), MG_DYN(3, 5, true, 64),
 };
 
 // Host twin of static_view<V>: the static view of (x, y, dir) as a table entry
@@ -1016,9 +1021,15 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   const Variant* var = nullptr;
   for (const Variant& v : kVariants)
     if (v.A == c.n_agents && v.V == c.view_size) var = &v;
+  // fully observed kinds never compute a view: they have instantiations of their own, whatever agent_view_size says
+  const bool want_full = c.env_kind == MG_KIND_MEETUP;
   const DynVariant* dvar = nullptr;
-  for (const DynVariant& v : kDynVariants)
-    if (v.A == c.n_agents && v.V == c.view_size) dvar = &v;
+  // among the matching instantiations: the smallest prefetch depth that covers the grid, else the deepest there is
+  const int gw = (c.width * c.height + 3) / 4;
+  for (const DynVariant& v : kDynVariants) {
+    if (v.A != c.n_agents || v.full != want_full || !(want_full || v.V == c.view_size)) continue;
+    if (!dvar || (dvar->pre < gw && v.pre > dvar->pre) || (v.pre >= gw && v.pre < dvar->pre)) dvar = &v;
+  }
   if (c.env_kind == MG_KIND_STATIC) {
     if (!var) return fail(MG_EUNSUPPORTED, "no kernel instantiated for this (n_agents, view_size)");
     if (c.kernel_path == MG_PATH_TABLE && !var->table[0]) return fail(MG_EUNSUPPORTED, "no table kernel for this view_size");
