@@ -190,7 +190,8 @@ int mg_destroy(mg_handle* h);
  * toggleable, nothing an agent can walk onto and destroy — multigrid.py:842-845,926-961).  Any key,
  * ball, box (empty), door or floor cell switches the handle to the mutable-grid kernel: every reset
  * copies the layout into the env's own grid (mg_buffers.grid) and step applies pickup / drop / toggle /
- * overlap to it (multigrid.py:926-961, 112-122, 834-847).  MG_EINVAL on a DOORKEY handle (no map). */
+ * overlap to it (multigrid.py:926-961, 112-122, 834-847).  MG_EINVAL on a generated kind (no map).  A new map
+ * invalidates the envs' state: mg_reset must be called again before the next step (MG_ESTATE otherwise). */
 int mg_set_static_map(mg_handle* h, const uint8_t* cells);
 
 /* env.reset() (multigrid.py:466-501) for every env whose mask byte is non-zero (mask = device

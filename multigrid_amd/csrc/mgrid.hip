@@ -995,6 +995,7 @@ int enable_dynamic(mg_handle* h, const std::vector<uint8_t>& kinds, int gx, int 
   h->gx = gx; h->gy = gy; h->LW = LW; h->LH = LH;
   h->dynamic = true; h->use_table = false; h->n_entries = 0;
   h->have_map = true;
+  h->have_reset = false;          // positions and grids of the old layout mean nothing on the new one
   h->buf.carry = h->carry; h->buf.grid = h->grid; h->buf.grid_words = h->GW; h->buf.mutable_grid = 1;
   return MG_OK;
 }
@@ -1250,6 +1251,7 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
   if (use_table) HIP_TRY(hipMemcpy(h->view_table, table.data(), table.size() * 4, hipMemcpyHostToDevice));
   h->use_table = use_table;
   h->have_map = true;
+  h->have_reset = false;          // positions and grids of the old layout mean nothing on the new one
   return MG_OK;
 }
 

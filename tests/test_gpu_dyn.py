@@ -206,6 +206,8 @@ def test_static_map_switches_back_to_shared_kernel(cluttered_cells):
   env.reset()
   env.step_random()
   _lib.check(env.L.mg_set_static_map(env.h, np.ascontiguousarray(cluttered_cells).ctypes.data_as(C.c_void_p)))
+  with pytest.raises(_lib.MgError):          # a new map invalidates the state: step needs a reset first
+    env.step_random()
   orc = c_oracle.OracleBatch(cluttered_cells, 200, shaping=1, auto_reset=1, seed=3)
   env.step_index = 0
   env.reset()
