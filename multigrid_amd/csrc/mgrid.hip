@@ -656,8 +656,10 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
     for (int i = tid; i < p.n_entries * ENTW / 4; i += blockDim.x) dst[i] = src[i];
     for (int i = tid; i < p.W * p.H; i += blockDim.x) cidx[i] = p.cell_index[i];
   }
+#if MG_ABL != 5   // (5: timing-only build without the LDS fills, to size the prologue)
   for (int i = tid; i < p.PW * p.PH; i += blockDim.x) map[i] = p.map_pad[i];
   for (int i = tid; i < p.W * p.H; i += blockDim.x) dist[i] = p.dist_lut[i];
+#endif
   __syncthreads();
 
   uint32_t* stage = stage_all + wv * (kWave * ROWB / 4);

@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
   const int A = dk_size ? dk_agents : 3, V = kind == MG_KIND_DOORKEY ? 7 : 5;
   // bytes one env-step has to move: obs + dir_done + rewards + actions + env_state r/w (+ carry, aux and grid r/w)
   const double obs_bytes = kind == MG_KIND_MEETUP ? dk_size * dk_size * 3 : A * V * V * 3;
-  const double env_bytes = obs_bytes + (A < 4 ? 4 : 8) + 8.0 * A + 4 + 8.0 * (A + 1) +
+  const double env_bytes = !dk_size ? 308.0 /* SURVEY §8(d) */ : obs_bytes + (A < 4 ? 4 : 8) + 8.0 * A + 4 + 8.0 * (A + 1) +
                            (dk_size ? 8 + 2.0 * ((dk_size * dk_size + 3) / 4 * 4) : 0) +
                            ((kind == MG_KIND_MEETUP || kind == MG_KIND_CLUTTERED) ? 32 : 0);
   std::vector<Api> apis;
