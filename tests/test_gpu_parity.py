@@ -402,3 +402,33 @@ def test_fast_instantiation_other_shapes(empty_cells, monkeypatch, A, V, n, grid
       _cmp_step(env, orc, 'fast (%d,%d) step %d' % (A, V, t))
   assert env.check_errors() == 0
   env.close()
+
+
+def test_rejection_sampling_fallback_parity():
+  """A map with exactly as many free cells as agents: the third spawn has one acceptable cell in 225, so the bounded
+  rejection loop (256 attempts) runs dry in about a third of the envs and the deterministic first-free-cell fallback
+  places the agent — identically on the device and in the oracle."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  cells = np.zeros((15, 15, 3), np.uint8)
+  cells[:, :] = (2, 5, 0)
+  for x, y in ((3, 4), (9, 2), (12, 12)):
+    cells[y, x] = (1, 0, 0)
+  n = 3000
+  env = BatchedMultiGrid(cells, n_envs=n, seed=13, emit_env_reward=True, kernel_path='generic')
+  orc = c_oracle.OracleBatch(cells, n, shaping=1, auto_reset=1, seed=13)
+  env.reset()
+  orc.reset()
+  _cmp(env, orc, 'reset')
+  # the fallback always yields direction 0: agent 2 faces east far more often than the 25 % of a drawn direction
+  dir0 = float((((orc.agent_state()[2, :n] >> 12) & 3) == 0).mean())
+  assert dir0 > 0.40, dir0
+  rng = np.random.RandomState(1)
+  for t in range(105):                      # includes the auto-reset at step 100
+    act = rng.randint(0, 7, size=(3, orc.stride)).astype(np.uint8)
+    env.step(torch.from_numpy(act).to(env.device))
+    orc.step(act)
+    if t % 10 == 0 or t >= 99:
+      _cmp_step(env, orc, 'step %d' % t)
+  assert env.check_errors() == 0
+  env.close()
