@@ -62,6 +62,16 @@ class Box:
     return 'Box(%r, %r, %r, %s)' % (self.low, self.high, self.shape, self.dtype)
 
 
+class Discrete:
+  """Stand-in for gym.spaces.Discrete metadata (n actions, scalar shape)."""
+
+  def __init__(self, n):
+    self.n, self.shape, self.dtype = n, (), 'int64'
+
+  def __repr__(self):
+    return 'Discrete(%d)' % self.n
+
+
 class RefCompatEnv:
   """One env (N = 1) with the reference's list-of-arrays contract; rewards are the unshaped env
   rewards unless the batched env was built with shaping='v8'."""
@@ -131,6 +141,9 @@ class VecAdapter:
     self.num_envs = batched.n_envs * batched.n_agents
     self.single_observation_shape = (batched.view_size * batched.view_size * 3 + 1,)
     self.single_action_n = 7
+    # the attributes ppo.py reads (ppo.py:165, 172-173, Agent.__init__): .shape of the obs space, .n / .shape of the action space
+    self.single_observation_space = Box(0, 255, self.single_observation_shape, 'uint8')
+    self.single_action_space = Discrete(7)
 
   def _obs(self):
     b = self.b

@@ -432,3 +432,30 @@ def test_rejection_sampling_fallback_parity():
       _cmp_step(env, orc, 'step %d' % t)
   assert env.check_errors() == 0
   env.close()
+
+
+def test_vec_adapter_contract(cluttered_cells):
+  """The gymnasium-vector shape ppo.py drives (ppo.py:162-208): agents flattened into the env axis, env-major."""
+  _need_gpu()
+  import multigrid_amd
+  from multigrid_amd.compat import VecAdapter
+  n = 96
+  env = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', n, seed=5)
+  orc = c_oracle.OracleBatch(cluttered_cells, n, shaping=1, auto_reset=1, seed=5)
+  vec = VecAdapter(env)
+  assert vec.num_envs == 3 * n and vec.single_observation_space.shape == (76,) and vec.single_action_space.n == 7
+  obs, info = vec.reset(seed=0)
+  orc.reset()
+  assert obs.shape == (3 * n, 76) and obs.dtype == torch.uint8 and info == {}
+  rng = np.random.RandomState(2)
+  for t in range(110):
+    flat = rng.randint(0, 7, size=3 * n)                         # sub-env k = env k // 3, agent k % 3
+    obs, rew, term, trunc, _ = vec.step(flat)
+    act = np.zeros((3, orc.stride), np.uint8)
+    act[:, :n] = flat.reshape(n, 3).T
+    orc.step(act)
+    want = np.concatenate([orc.obs_image[:, :n], orc.obs_dir[:, :n, None]], axis=-1).transpose(1, 0, 2).reshape(3 * n, 76)
+    assert np.array_equal(obs.cpu().numpy(), want), t
+    assert np.array_equal(rew.cpu().numpy().view(np.int64), orc.reward[:, :n].T.reshape(-1).view(np.int64)), t
+    assert np.array_equal(trunc.cpu().numpy(), np.repeat(orc.done[:n].astype(bool), 3)) and not term.any()
+  env.close()
