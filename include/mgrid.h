@@ -194,6 +194,19 @@ int mg_destroy(mg_handle* h);
  * invalidates the envs' state: mg_reset must be called again before the next step (MG_ESTATE otherwise). */
 int mg_set_static_map(mg_handle* h, const uint8_t* cells);
 
+/* Fixed start cells on a static map (shared-map kernels only).  xy = host int8[A][2].
+ *   MG_FIXED_ALWAYS   EmptyEnv(agent_start='fixed').place_one_agent (multigrid_envs/empty.py:33-36, 72-104): every
+ *                     placement — reset and the respawn after a goal / lava touch — puts the agent on its start cell
+ *                     facing east; an agent found on that cell is sent back to its own start cell first (and so on).
+ *   MG_FIXED_AT_RESET MazeEnv._gen_grid (multigrid_envs/maze.py:86): reset places the agent on its start cell with a
+ *                     drawn direction; respawns stay random (multigrid.py:832).
+ *   MG_FIXED_OFF      back to random placement.
+ * A later mg_set_static_map switches it off again; mg_reset is required afterwards. */
+#define MG_FIXED_OFF      0
+#define MG_FIXED_ALWAYS   1
+#define MG_FIXED_AT_RESET 2
+int mg_set_fixed_spawn(mg_handle* h, const int8_t* xy, int mode);
+
 /* env.reset() (multigrid.py:466-501) for every env whose mask byte is non-zero (mask = device
  * pointer uint8[n_envs], or NULL for all).  Spawns are drawn on device (Philox) with the
  * reference's distribution: uniform rejection sampling over the grid for an empty cell not

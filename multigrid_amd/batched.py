@@ -33,12 +33,15 @@ class BatchedMultiGrid:
   def __init__(self, cells, n_envs, n_agents=3, view_size=5, max_steps=100, see_through_walls=False,
                competitive=False, shaping='v8', auto_reset=True, device=0, seed=0,
                env_id_base=0, emit_env_reward=False, use_torch_stream=True, kernel_path='auto',
-               kind='static', size=None, n_goals=0, n_clutter=0, walls_are_lava=False):
+               kind='static', size=None, n_goals=0, n_clutter=0, walls_are_lava=False, fixed_spawn=None,
+               fixed_mode='always'):
     """kind='static': `cells` uint8[H, W, 3] is the layout every reset starts from (objects allowed).
     kind='doorkey' | 'cluttered' | 'meetup': `cells` is None and `size` the grid size; layouts are drawn
     on device per env and per reset.  cluttered: n_goals = 1 for randomize_goal (0: goal at (size-2, size-2)),
     n_clutter obstacles (lava with walls_are_lava); meetup: n_goals goal doors (1..3), n_clutter walls,
-    fully observed (`obs_full`, `obs_image` is None)."""
+    fully observed (`obs_full`, `obs_image` is None).
+    fixed_spawn: [(x, y)] * n_agents start cells on a static map; fixed_mode 'always' = EmptyEnv's fixed start
+    (empty.py:72-104), 'reset' = MazeEnv's (maze.py:86)."""
     self.L = _lib.load()
     self.kind = kind
     if kind == 'static':
@@ -65,6 +68,10 @@ class BatchedMultiGrid:
     self.cells = cells
     if kind == 'static':
       _lib.check(self.L.mg_set_static_map(self.h, cells.ctypes.data_as(C.c_void_p)))
+    if fixed_spawn is not None:
+      xy = np.ascontiguousarray(fixed_spawn, dtype=np.int8).reshape(self.n_agents, 2)
+      _lib.check(self.L.mg_set_fixed_spawn(self.h, xy.ctypes.data_as(C.c_void_p),
+                                           {'always': _lib.FIXED_ALWAYS, 'reset': _lib.FIXED_AT_RESET}[fixed_mode]))
     if use_torch_stream:
       s = torch.cuda.current_stream(self.device)
       _lib.check(self.L.mg_set_stream(self.h, C.c_void_p(s.cuda_stream)))

@@ -95,6 +95,8 @@ struct Params {
   uint32_t* grid;              // [n_chunks][GW][64]
   int32_t n_goals, n_clutter, gen_flags, full_obs;   // scatter generators (CLUTTERED, MEETUP)
   int32_t gx, gy, LW, LH;      // shaper goal and the dims of the mutable-grid kernel's |dx|,|dy| distance LUT
+  int32_t fixed_mode, fixed_pad;   // MG_FIXED_*: agents (re)start on fixed cells (shared-map kernels)
+  uint64_t fixed_pd;           // their start cells, packed like pd (x | y<<6 per agent, 14 bits each)
   const uint16_t* scatter;     // int8x2 per (env, scattered object): injected layout draws
   uint32_t* aux;               // [stride][4]  MEETUP goal positions + past distances
   uint8_t* obs_full;           // [stride][W*H*3]  fully observed obs
@@ -360,12 +362,16 @@ __device__ __forceinline__ uint32_t asm_load_u32(const void* ptr) {
 // FAST = the hot configuration, known at compile time: a free-running step() whose actions come
 // from HBM (no replay injection, no on-device action draw, no env_reward output).  Everything
 // else (reset, replay, step_random, emit_env_reward) runs the general instantiation.
-template <int A, bool FAST>
-__device__ __forceinline__ void load_chunk(const Params& p, int64_t env0, int lane, ChunkIn& in) {
-  const int64_t n = env0 + lane;
+__device__ __forceinline__ void zero_chunk(ChunkIn& in) {
   in.q = u32x4{0, 0, 0, 0};
   in.w0 = in.w1 = in.w2 = in.w3 = in.w4 = 0u;
   in.act = 0x06060606u;
+}
+
+template <int A, bool FAST>
+__device__ __forceinline__ void load_chunk(const Params& p, int64_t env0, int lane, ChunkIn& in) {
+  const int64_t n = env0 + lane;
+  zero_chunk(in);
   if (A == 3) {
     const void* ptr = reinterpret_cast<const uint4*>(p.env_state) + n;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(in.q) : "v"(ptr) : "memory");
@@ -480,6 +486,27 @@ __device__ __forceinline__ uint32_t v8_shape(const Params& p, const double* dist
   return ((uint32_t)x << 14) | ((uint32_t)y << 20) | (1u << 26) | (stat << 27);   // v8:218
 }
 
+// EmptyEnv.place_one_agent with agent_start='fixed' (multigrid_envs/empty.py:72-104): agent a goes to its start cell
+// facing east; whoever stands there is sent back to its own start cell first, and so on down the chain.  on_grid =
+// agents that currently have a cell (the finishing agent was taken off the grid before, multigrid.py:817-819).
+template <int A>
+__device__ __forceinline__ uint64_t fixed_place(const Params& p, uint64_t pd, int a, uint32_t on_grid) {
+  int t = a;
+#pragma unroll 1
+  for (int it = 0; it < A; ++it) {
+    const uint32_t spos = pd_get(p.fixed_pd, t) & AW_POS;
+    int b = -1;
+#pragma unroll
+    for (int c = 0; c < A; ++c)
+      if (c != t && ((on_grid >> c) & 1u) && (pd_get(pd, c) & AW_POS) == spos) b = c;
+    pd = pd_set(pd, t, spos);                       // agent_start_dir = 0
+    on_grid |= 1u << t;
+    if (b < 0) break;
+    t = b;
+  }
+  return pd;
+}
+
 // One chunk (64 envs) of one step()/reset().
 template <int A, int V, bool TAB, bool FAST>
 __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, const double* dist, const uint32_t* table,
@@ -546,9 +573,14 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
       if (go && (cell & F_KILL)) {                                            // goal or lava: agent_is_done :815-832
         dbits |= 1u << a;
         if (cell & F_GOAL) gbits |= 1u << a;                                  // cell re-read is still the goal :881-883
-        const uint32_t w = place_agent<A>(p, map, pd, ((1u << A) - 1u) & ~(1u << a), a, P_RESPAWN, inj_respawn, n, gid);
-        npd = w & AW_POSDIR;
-        err |= w >> 16;
+        if (p.fixed_mode == MG_FIXED_ALWAYS) {
+          pd = fixed_place<A>(p, pd, a, ((1u << A) - 1u) & ~(1u << a));
+          npd = pd_get(pd, a);
+        } else {
+          const uint32_t w = place_agent<A>(p, map, pd, ((1u << A) - 1u) & ~(1u << a), a, P_RESPAWN, inj_respawn, n, gid);
+          npd = w & AW_POSDIR;
+          err |= w >> 16;
+        }
       }
       if (act > 6u) err |= MG_ERR_BAD_ACTION;                                 // assert False :902
       pd = pd_set(pd, a, npd);
@@ -588,9 +620,17 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
   if (do_reset) {
 #pragma unroll 1
     for (int a = 0; a < A; ++a) {
-      const uint32_t w = place_agent<A>(p, map, pd, (1u << a) - 1u, a, P_SPAWN, inj_spawn, n, gid);
-      pd = pd_set(pd, a, w & AW_POSDIR);
-      err |= w >> 16;
+      if (p.fixed_mode == MG_FIXED_ALWAYS) {
+        pd = fixed_place<A>(p, pd, a, (1u << a) - 1u);
+      } else if (p.fixed_mode == MG_FIXED_AT_RESET) {       // MazeEnv: place_agent_at_pos(start_pos), direction drawn (maze.py:86)
+        const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), ((uint32_t)P_SPAWN << 28) | ((uint32_t)a << 20),
+                            p.seed_lo, p.seed_hi);
+        pd = pd_set(pd, a, (pd_get(p.fixed_pd, a) & AW_POS) | ((r.z >> 30) << 12));
+      } else {
+        const uint32_t w = place_agent<A>(p, map, pd, (1u << a) - 1u, a, P_SPAWN, inj_spawn, n, gid);
+        pd = pd_set(pd, a, w & AW_POSDIR);
+        err |= w >> 16;
+      }
     }
 #pragma unroll
     for (int a = 0; a < A; ++a) shw[a] = 0u;          // shaper state cleared (v8:227-229)
@@ -648,6 +688,7 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
   const int64_t cstride = (int64_t)gridDim.x * nw;
   int64_t c = (int64_t)blockIdx.x * nw + wv;
   ChunkIn cur, nxt;
+  zero_chunk(cur);
   if (c < p.n_chunks) load_chunk<A, FAST>(p, c * kWave, lane, cur);
 
   if (TAB) {
@@ -673,25 +714,25 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
   constexpr int kObs = 0;
 #endif
   constexpr int kStep = (kObs + 2 + A) < 63 ? (kObs + 2 + A) : 63, kReset = (kObs + 2) < 63 ? (kObs + 2) : 63;
-  // (only for the benchmark shape: for larger bodies hipcc does not unroll the loops below, indexes in[] at run
-  // time, keeps it in scratch and would store the registers there while their loads are still in flight —
-  // tools/isa_prefetch_lint.py, run by tests/test_isa_lint.py, checks every kernel for that)
-  constexpr bool kCanUpfront = A == 3 && V == 5;
+  constexpr bool kCanUpfront = A == 3 && V == 5;    // the benchmark shape only: four more inlined copies of do_chunk
   if (FAST && kCanUpfront && p.n_chunks <= cstride * kUpfront) {
     // Launch-resident batch (at most kUpfront chunks per wave): fetch ALL inputs first, then only
     // store.  The whole chip then runs one read burst followed by an uninterrupted write stream,
     // which the memory system serves faster than reads interleaved with writes.
-    ChunkIn in[kUpfront];
-    in[0] = cur;
-#pragma unroll
-    for (int k = 1; k < kUpfront; ++k)
-      if (c + k * cstride < p.n_chunks) load_chunk<A, FAST>(p, (c + k * cstride) * kWave, lane, in[k]);
-#pragma unroll
-    for (int k = 0; k < kUpfront; ++k) wait_chunk<0>(in[k]);
-#pragma unroll
-    for (int k = 0; k < kUpfront; ++k)
-      if (c + k * cstride < p.n_chunks)
-        do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, (c + k * cstride) * kWave, in[k], err);
+    // (named variables, not an array: whether a loop over an array unrolls depends on the size of do_chunk, and an
+    // array indexed at run time lives in scratch, where it would be stored while its loads are still in flight)
+    static_assert(kUpfront == 4, "four explicit slots below");
+    const bool h1 = c + 1 * cstride < p.n_chunks, h2 = c + 2 * cstride < p.n_chunks, h3 = c + 3 * cstride < p.n_chunks;
+    ChunkIn in1, in2, in3;
+    zero_chunk(in1); zero_chunk(in2); zero_chunk(in3);
+    if (h1) load_chunk<A, FAST>(p, (c + 1 * cstride) * kWave, lane, in1);
+    if (h2) load_chunk<A, FAST>(p, (c + 2 * cstride) * kWave, lane, in2);
+    if (h3) load_chunk<A, FAST>(p, (c + 3 * cstride) * kWave, lane, in3);
+    wait_chunk<0>(cur); wait_chunk<0>(in1); wait_chunk<0>(in2); wait_chunk<0>(in3);
+    if (c < p.n_chunks) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, c * kWave, cur, err);
+    if (h1) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, (c + 1 * cstride) * kWave, in1, err);
+    if (h2) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, (c + 2 * cstride) * kWave, in2, err);
+    if (h3) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, (c + 3 * cstride) * kWave, in3, err);
   } else {
     if (c < p.n_chunks) wait_chunk<0>(cur);
     for (; c < p.n_chunks; c += cstride) {
@@ -830,6 +871,8 @@ struct mg_handle {
   uint8_t* obs_full;
   bool full_obs;
   int dyn_waves_cu;      // waves of the mutable-grid kernel a CU can hold by registers
+  int fixed_mode; uint64_t fixed_pd;       // mg_set_fixed_spawn
+  std::vector<uint8_t> free_cells;         // host copy: cell (y*W + x) holds nothing (placement checks)
   int LW, LH;            // dims of the mutable-grid kernel's relative distance LUT
   mg_buffers buf;
   std::vector<void*> allocs;
@@ -942,6 +985,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   p.carry = h->carry; p.grid = h->grid;
   p.n_goals = c.gen_n_goals; p.n_clutter = c.gen_n_clutter; p.gen_flags = c.gen_flags; p.full_obs = h->full_obs ? 1 : 0;
   p.gx = h->gx; p.gy = h->gy; p.LW = h->LW; p.LH = h->LH;
+  p.fixed_mode = h->fixed_mode; p.fixed_pd = h->fixed_pd;
   p.scatter = reinterpret_cast<const uint16_t*>(scatter); p.aux = h->aux; p.obs_full = h->obs_full;
   int nw; unsigned grid; size_t lds;
   DeviceGuard g(h->device);
@@ -1066,7 +1110,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   h->dynamic = false; h->dvar = dvar; h->GW = (c.width * c.height + 3) / 4;
   h->base_grid = nullptr; h->carry = nullptr; h->grid = nullptr; h->aux = nullptr; h->obs_full = nullptr;
   h->full_obs = c.env_kind == MG_KIND_MEETUP; h->LW = c.width; h->LH = c.height;
-  h->dyn_waves_cu = 8;
+  h->dyn_waves_cu = 8; h->fixed_mode = 0; h->fixed_pd = 0;
   if (dvar) {
     hipFuncAttributes fa;
     if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(dvar->fn)) == hipSuccess && fa.numRegs > 0) {
@@ -1160,6 +1204,9 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
     // any object an agent can pick up, toggle or walk onto and destroy -> per-env mutable grids
     bool objects = false;
     std::vector<uint8_t> kinds((size_t)W * H, 0);
+    h->free_cells.assign((size_t)W * H, 0);
+    for (int i = 0; i < W * H; ++i) h->free_cells[i] = cells[(size_t)i * 3] <= MG_T_EMPTY;
+    h->fixed_mode = 0;                      // start cells belong to the old layout
     int n_free = 0, gx = -1, gy = -1;
     for (int i = 0; i < W * H; ++i) {
       const uint8_t* c = cells + (size_t)i * 3;
@@ -1254,6 +1301,25 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
   h->use_table = use_table;
   h->have_map = true;
   h->have_reset = false;          // positions and grids of the old layout mean nothing on the new one
+  return MG_OK;
+}
+
+int mg_set_fixed_spawn(mg_handle* h, const int8_t* xy, int mode) {
+  if (!h) return fail(MG_EINVAL, "null handle");
+  if (mode == MG_FIXED_OFF) { h->fixed_mode = 0; return MG_OK; }
+  if (!xy || (mode != MG_FIXED_ALWAYS && mode != MG_FIXED_AT_RESET)) return fail(MG_EINVAL, "bad argument");
+  if (h->cfg.env_kind != MG_KIND_STATIC || !h->have_map) return fail(MG_ESTATE, "fixed start cells need a static map (mg_set_static_map first)");
+  if (h->dynamic) return fail(MG_EUNSUPPORTED, "fixed start cells are not implemented for mutable grids");
+  const int W = h->cfg.width, H = h->cfg.height, A = h->cfg.n_agents;
+  uint64_t pd = 0;
+  for (int a = 0; a < A; ++a) {
+    const int x = xy[2 * a], y = xy[2 * a + 1];
+    if (x < 0 || y < 0 || x >= W || y >= H || !h->free_cells[(size_t)y * W + x]) return fail(MG_EINVAL, "start cell is not a free cell of the map");
+    for (int b = 0; b < a; ++b)
+      if (xy[2 * b] == x && xy[2 * b + 1] == y) return fail(MG_EINVAL, "two agents share a start cell");
+    pd |= (uint64_t)((uint32_t)x | ((uint32_t)y << 6)) << (14 * a);
+  }
+  h->fixed_pd = pd; h->fixed_mode = mode; h->have_reset = false;
   return MG_OK;
 }
 

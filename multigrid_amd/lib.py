@@ -13,6 +13,7 @@ KIND_STATIC, KIND_DOORKEY, KIND_CLUTTERED, KIND_MEETUP, KIND_FOURROOMS = 0, 1, 2
 KINDS = {'static': KIND_STATIC, 'doorkey': KIND_DOORKEY, 'cluttered': KIND_CLUTTERED, 'meetup': KIND_MEETUP,
          'fourrooms': KIND_FOURROOMS}
 GEN_LAVA = 1
+FIXED_OFF, FIXED_ALWAYS, FIXED_AT_RESET = 0, 1, 2
 
 
 def kind_id(type_, color=0, state=0):
@@ -50,6 +51,7 @@ SYMBOLS = {
     'mg_create': (C.c_int, [C.POINTER(MgConfig), C.c_int, C.POINTER(C.c_void_p)]),
     'mg_destroy': (C.c_int, [C.c_void_p]),
     'mg_set_static_map': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mg_set_fixed_spawn': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     'mg_reset': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_reset_inject': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'mg_step': (C.c_int, [C.c_void_p, C.c_void_p]),

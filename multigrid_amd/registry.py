@@ -31,11 +31,17 @@ register('MultiGrid-Cluttered-Fixed-15x15', dict(
     see_through_walls=False, competitive=False))
 
 # EmptyEnv with agent_start='random' (multigrid_envs/empty.py:28-60, 106-117): border walls, goal at (size-2, size-2),
-# agents anywhere, view 5, see_through_walls=True, max_steps 2*size^2 — a static layout.  The fixed-start ids
-# (agents always re-placed on their start cells, empty.py:80-89) are not registered.
+# agents anywhere, view 5, see_through_walls=True, max_steps 2*size^2 — a static layout.
 for _id, _size, _agents in (('MultiGrid-Empty-Random-5x5-v0', 5, 2), ('MultiGrid-Empty-Random-8x8-v0', 8, 3)):
   register(_id, dict(layout=(lambda n=_size: layouts.empty_bordered(n, n, goal=(n - 2, n - 2))), n_agents=_agents, view_size=5,
                      max_steps=2 * _size * _size, see_through_walls=True, competitive=False))
+
+# EmptyEnv with the default agent_start='fixed' (empty.py:28-36, 72-104): agents (re)start on (1, 1+i) facing east.
+# The 16x16 id has five agents (not instantiated).
+for _id, _size, _agents in (('MultiGrid-Empty-5x5-v0', 5, 2), ('MultiGrid-Empty-8x8-v0', 8, 3), ('MultiGrid-Empty-5x5-Single-v0', 5, 1)):
+  register(_id, dict(layout=(lambda n=_size: layouts.empty_bordered(n, n, goal=(n - 2, n - 2))), n_agents=_agents, view_size=5,
+                     max_steps=2 * _size * _size, see_through_walls=True, competitive=False,
+                     fixed_spawn=[(1, 1 + _i) for _i in range(_agents)], fixed_mode='always'))
 
 # DoorKeyEnv family (multigrid_envs/doorkey.py:27-161): view 7 (multigrid.py:333 default),
 # max_steps 10*size^2, layouts drawn per env and per reset on device.  The 16x16 five-agent id is

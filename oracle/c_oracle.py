@@ -75,6 +75,7 @@ def lib():
     L.mgo_batch_step_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, u8p, i8p, i8p, i8p, i8p,
                                     C.c_uint64, u8p, u8p, f64p, f64p, u8p, u8p]
     L.mgo_batch_dyn_state.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_void_p, u8p]
+    L.mgo_set_fixed_spawn.argtypes = [C.c_void_p, i8p, C.c_int]
     L.mgo_set_scatter.restype = C.c_int
     L.mgo_set_scatter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.mgo_obs_bytes.restype = C.c_int
@@ -96,7 +97,13 @@ KINDS = {'static': KIND_STATIC, 'doorkey': KIND_DOORKEY, 'cluttered': KIND_CLUTT
 MAXOBJ = 64
 
 
-def _configure(L, h, kind, n_goals, n_clutter, lava):
+FIXED_ALWAYS, FIXED_AT_RESET = 1, 2     # mgo_set_fixed_spawn modes (EmptyEnv fixed start / MazeEnv)
+
+
+def _configure(L, h, kind, n_goals, n_clutter, lava, fixed_spawn=None, fixed_mode=0):
+  if fixed_spawn is not None:
+    xy = np.ascontiguousarray(fixed_spawn, np.int8)
+    L.mgo_set_fixed_spawn(h, _p(xy, i8p), fixed_mode)
   L.mgo_set_kind(h, KINDS[kind])
   if kind in ('cluttered', 'meetup'):
     if not L.mgo_set_scatter(h, n_goals, n_clutter, int(lava)):
@@ -148,13 +155,14 @@ class OracleEnv:
   """One oracle env with the reference's (obs, rewards, done, info) call shape."""
 
   def __init__(self, cells, W=15, H=15, A=3, V=5, max_steps=100, see_through=0, competitive=0,
-               shaping=0, auto_reset=0, seed=0, gid=0, kind='static', n_goals=0, n_clutter=0, lava=False):
+               shaping=0, auto_reset=0, seed=0, gid=0, kind='static', n_goals=0, n_clutter=0, lava=False,
+               fixed_spawn=None, fixed_mode=0):
     self.L = lib()
     self.W, self.H, self.A, self.V = W, H, A, V
     self.h = self.L.mgo_create(W, H, A, V, max_steps, see_through, competitive, shaping, auto_reset, seed, gid)
     if not self.h:
       raise ValueError('bad oracle config')
-    _configure(self.L, self.h, kind, n_goals, n_clutter, lava)
+    _configure(self.L, self.h, kind, n_goals, n_clutter, lava, fixed_spawn, fixed_mode)
     self.n_obj = (n_goals + n_clutter) if kind in ('cluttered', 'meetup') else (3 if kind == 'fourrooms' else 0)
     self.full = kind == 'meetup'
     self.img_shape = (W, H, 3) if self.full else (V, V, 3)
@@ -283,7 +291,8 @@ class OracleBatch:
   """n oracle envs over the product's buffer layouts."""
 
   def __init__(self, cells, n, W=15, H=15, A=3, V=5, max_steps=100, see_through=0, competitive=0,
-               shaping=0, auto_reset=0, seed=0, gid_base=0, kind='static', n_goals=0, n_clutter=0, lava=False):
+               shaping=0, auto_reset=0, seed=0, gid_base=0, kind='static', n_goals=0, n_clutter=0, lava=False,
+               fixed_spawn=None, fixed_mode=0):
     self.L = lib()
     self.n, self.A, self.V, self.W, self.H = n, A, V, W, H
     self.n_obj = (n_goals + n_clutter) if kind in ('cluttered', 'meetup') else (3 if kind == 'fourrooms' else 0)
@@ -295,7 +304,7 @@ class OracleBatch:
       h = self.L.mgo_create(W, H, A, V, max_steps, see_through, competitive, shaping, auto_reset, seed, gid_base + i)
       if not h:
         raise ValueError('bad oracle config')
-      _configure(self.L, h, kind, n_goals, n_clutter, lava)
+      _configure(self.L, h, kind, n_goals, n_clutter, lava, fixed_spawn, fixed_mode)
       if cells is not None:
         self.L.mgo_set_map(h, _p(cells, u8p))
       self.envs[i] = h

@@ -124,6 +124,10 @@ typedef struct mgo_env {
   int goal_x[MAXGOALS], goal_y[MAXGOALS];   /* MeetupEnv.goal_pos (meetup.py:67-70) */
   int past_dist[MAXA];         /* MeetupEnv.past_goal_dist (meetup.py:61, 94) */
   const int8_t* inj_scatter;   /* injected accepted (x, y) of every scattered object, in draw order, or NULL */
+  /* fixed start cells: mode 1 = EmptyEnv agent_start='fixed' (empty.py:33-36,72-89): every placement puts the agent
+   * on its start cell facing east, whoever stands there goes back to its own start first; mode 2 = MazeEnv
+   * (maze.py:86): reset places the agent on its start cell with a drawn direction, respawns stay random */
+  int fixed_mode; int fixed_x[MAXA], fixed_y[MAXA];
   int8_t last_scatter[2 * MAXOBJ]; int n_scatter;
 } mgo_env;
 
@@ -148,6 +152,11 @@ int mgo_set_scatter(mgo_env* e, int n_goals, int n_clutter, int lava) {
 }
 int mgo_obs_bytes(const mgo_env* e) { return e->full_obs ? e->W * e->H * 3 : e->V * e->V * 3; }
 void mgo_destroy(mgo_env* e) { free(e); }
+/* xy: [A][2] start cells; mode 0 switches the feature off */
+void mgo_set_fixed_spawn(mgo_env* e, const int8_t* xy, int mode) {
+  e->fixed_mode = mode;
+  for (int a = 0; a < e->A && xy; ++a) { e->fixed_x[a] = xy[2 * a]; e->fixed_y[a] = xy[2 * a + 1]; }
+}
 
 /* cells: uint8[W*H*3], [(y*W+x)*3+c]; type 1 (empty) and 0 mean None */
 void mgo_set_map(mgo_env* e, const uint8_t* cells) {
@@ -199,6 +208,23 @@ static int cell_free(const mgo_env* e, int x, int y) {
 
 /* place_one_agent (multigrid.py:646-661) + place_agent_at_pos (multigrid.py:663-675) */
 static void place_one_agent(mgo_env* e, int a) {
+  if (e->fixed_mode == 1 || (e->fixed_mode == 2 && e->purpose == P_SPAWN)) {
+    const int sx = e->fixed_x[a], sy = e->fixed_y[a];
+    int dir = 0;                                       /* agent_start_dir = [0] * n_agents, empty.py:35 */
+    if (e->fixed_mode == 1) {
+      obj_t other = grid_get(&e->grid, sx, sy);        /* empty.py:82-85: move whoever is on my start cell back to its own */
+      if (other.type == T_AGENT && other.color != a) place_one_agent(e, other.color);
+    } else {
+      int cx, cy;
+      draw_candidate(e, a, 0, &cx, &cy, &dir);         /* place_agent_at_pos(0, start_pos): only the direction is drawn */
+    }
+    int8_t* rec = (e->purpose == P_SPAWN ? e->last_spawn : e->last_respawn) + 4 * a;
+    rec[0] = (int8_t)sx; rec[1] = (int8_t)sy; rec[2] = (int8_t)dir; rec[3] = 0;
+    e->ax[a] = sx; e->ay[a] = sy; e->has_pos[a] = 1; e->adir[a] = dir;
+    obj_t ag = {T_AGENT, (uint8_t)a, (uint8_t)dir, 0};
+    grid_set(&e->grid, sx, sy, ag);
+    return;
+  }
   e->has_pos[a] = 0;                                   /* multigrid.py:655 */
   int x = -1, y = -1, dir = 0;
   if (e->inj) {                                        /* replay: the accepted draw is injected */

@@ -491,6 +491,62 @@ class PyDoorKeyEnv(PyRefEnv):
     return super().place_one_agent(agent_id, agent_obj=agent_obj, size=size)
 
 
+class PyEmptyFixedEnv(PyRefEnv):
+  """EmptyEnv with agent_start='fixed' (multigrid_envs/empty.py:28-104): agents always (re)start on (1, 1+i) facing
+  east; an agent found on another one's start cell is sent back to its own first."""
+
+  def __init__(self, size=5, n_agents=2, view_size=5, **kw):
+    assert n_agents < size - 2
+    self.agent_start_pos = [np.array([1, i]) for i in range(1, n_agents + 1)]
+    self.agent_start_dir = [0] * n_agents
+    layout = np.zeros((size, size, 3), np.uint8)
+    layout[:, :, 0] = 1
+    layout[0, :] = layout[-1, :] = (2, 5, 0)
+    layout[:, 0] = layout[:, -1] = (2, 5, 0)
+    layout[size - 2, size - 2] = (8, 1, 0)
+    super().__init__(layout, n_agents=n_agents, view_size=view_size, max_steps=2 * size * size, see_through_walls=True, **kw)
+
+  def place_one_agent(self, agent_id, agent_obj=None, size=None):
+    pos = self.agent_start_pos[agent_id]
+    other = self.grid.get(pos[0], pos[1])
+    if other:                                                            # empty.py:82-85
+      self.place_one_agent(other.agent_id, agent_obj=other)
+    self.agent_pos[agent_id] = pos
+    self.agent_dir[agent_id] = self.agent_start_dir[agent_id]
+    if not agent_obj:
+      agent_obj = AgentObj(agent_id, self.agent_dir[agent_id])
+    else:
+      agent_obj.dir = self.agent_dir[agent_id]
+    self.grid.set(pos[0], pos[1], agent_obj)
+    return pos
+
+
+class PyBitmapMazeEnv(PyRefEnv):
+  """MazeEnv (multigrid_envs/maze.py:27-99) for a caller-supplied bitmap: one agent placed on a fixed start cell with a
+  drawn direction at every reset (place_agent_at_pos, maze.py:86), goal on a fixed cell, see_through_walls."""
+
+  def __init__(self, bit_map, start_pos, goal_pos, view_size=5, **kw):
+    bit_map = np.asarray(bit_map)
+    size = bit_map.shape[0] + 2
+    layout = np.zeros((size, size, 3), np.uint8)
+    layout[:, :, 0] = 1
+    layout[0, :] = layout[-1, :] = (2, 5, 0)
+    layout[:, 0] = layout[:, -1] = (2, 5, 0)
+    layout[1:-1, 1:-1][bit_map.astype(bool)] = (2, 5, 0)
+    layout[goal_pos[1], goal_pos[0]] = (8, 1, 0)
+    self.start_pos = np.array(start_pos)
+    super().__init__(layout, n_agents=1, view_size=view_size, max_steps=2 * size * size, see_through_walls=True, **kw)
+
+  def _gen_grid(self):
+    self.grid = CellGrid(self.width, self.height)
+    for y in range(self.height):
+      for x in range(self.width):
+        self.grid.set(x, y, decode_cell(*self.layout[y, x]))
+    self.agent_pos[0] = self.start_pos                                   # place_agent_at_pos(0, start_pos)
+    self.agent_dir[0] = self.rand_int(0, 4)
+    self.grid.set(self.start_pos[0], self.start_pos[1], AgentObj(0, self.agent_dir[0]))
+
+
 class PyClutteredEnv(PyRefEnv):
   """ClutteredMultiGrid with a fresh layout per reset (multigrid_envs/cluttered.py:13-45): border walls,
   goal (random or at (w-2,h-2)), n_clutter walls or lava scattered by place_obj, agents anywhere."""

@@ -459,3 +459,73 @@ def test_vec_adapter_contract(cluttered_cells):
     assert np.array_equal(rew.cpu().numpy().view(np.int64), orc.reward[:, :n].T.reshape(-1).view(np.int64)), t
     assert np.array_equal(trunc.cpu().numpy(), np.repeat(orc.done[:n].astype(bool), 3)) and not term.any()
   env.close()
+
+
+@pytest.mark.parametrize('size,A,n', [(5, 2, 1500), (8, 3, 2000), (5, 1, 500)])
+def test_fixed_start_empty_parity(size, A, n):
+  """EmptyEnv with fixed start cells (empty.py:72-104): every (re)placement on (1, 1+i) facing east, displaced agents
+  chained back to their own start cells; see_through_walls."""
+  _need_gpu()
+  from multigrid_amd import layouts
+  from multigrid_amd.batched import BatchedMultiGrid
+  cells = layouts.empty_bordered(size, size, goal=(size - 2, size - 2))
+  starts = [(1, 1 + i) for i in range(A)]
+  for emit in (True, False):           # general and FAST instantiation
+    env = BatchedMultiGrid(cells, n_envs=n, n_agents=A, view_size=5, max_steps=2 * size * size, see_through_walls=True,
+                           seed=3, emit_env_reward=emit, fixed_spawn=starts, fixed_mode='always')
+    orc = c_oracle.OracleBatch(cells, n, W=size, H=size, A=A, V=5, max_steps=2 * size * size, see_through=1, shaping=1,
+                               auto_reset=1, seed=3, fixed_spawn=starts, fixed_mode=c_oracle.FIXED_ALWAYS)
+    env.reset()
+    orc.reset()
+    _cmp(env, orc, 'reset')
+    rng = np.random.RandomState(4)
+    touches = 0
+    for t in range(160):
+      act = rng.choice(7, size=(A, orc.stride), p=[.15, .15, .5, .05, .05, .05, .05]).astype(np.uint8)
+      env.step(torch.from_numpy(act).to(env.device))
+      orc.step(act)
+      _cmp_step(env, orc, 'step %d' % t)
+      touches += int((orc.env_reward[:, :n] > 0).sum())
+    assert env.check_errors() == 0 and touches > 0
+    env.close()
+
+
+def test_fixed_start_at_reset_maze_parity():
+  """MazeEnv-style start (maze.py:86): a caller-supplied bitmap, the agent on a fixed cell with a drawn direction at
+  every reset, random respawn otherwise; plus the argument checks of mg_set_fixed_spawn."""
+  _need_gpu()
+  from multigrid_amd import layouts, lib
+  from multigrid_amd.batched import BatchedMultiGrid
+  cells = layouts.empty_bordered(8, 8, goal=(6, 6))
+  bitmap = np.array([[0, 0, 1, 0, 0, 0], [0, 1, 1, 0, 1, 0], [0, 0, 0, 0, 1, 0],
+                     [1, 1, 0, 1, 1, 0], [0, 0, 0, 0, 0, 0], [0, 1, 1, 1, 0, 0]], bool)
+  cells[1:-1, 1:-1][bitmap] = (2, 5, 0)
+  n = 1500
+  env = BatchedMultiGrid(cells, n_envs=n, n_agents=1, view_size=5, max_steps=128, see_through_walls=True, seed=6,
+                         emit_env_reward=True, fixed_spawn=[(1, 1)], fixed_mode='reset')
+  orc = c_oracle.OracleBatch(cells, n, W=8, H=8, A=1, V=5, max_steps=128, see_through=1, shaping=1, auto_reset=1, seed=6,
+                             fixed_spawn=[(1, 1)], fixed_mode=c_oracle.FIXED_AT_RESET)
+  env.reset()
+  orc.reset()
+  _cmp(env, orc, 'reset')
+  assert (env.agent_pos.cpu().numpy() == 1).all() and len(set(env.agent_dir.cpu().numpy().ravel().tolist())) == 4
+  rng = np.random.RandomState(7)
+  for t in range(200):
+    act = rng.choice(7, size=(1, orc.stride), p=[.2, .2, .5, .025, .025, .025, .025]).astype(np.uint8)
+    env.step(torch.from_numpy(act).to(env.device))
+    orc.step(act)
+    _cmp_step(env, orc, 'step %d' % t)
+  assert env.check_errors() == 0
+  import ctypes as C
+  bad = np.array([[2, 2]], np.int8)           # (2,2) is a wall of the bitmap
+  assert env.L.mg_set_fixed_spawn(env.h, bad.ctypes.data_as(C.c_void_p), lib.FIXED_ALWAYS) != 0
+  env.close()
+  env = multigrid_amd_make('MultiGrid-Empty-8x8-v0')
+  env.reset(); env.step_random()
+  assert env.check_errors() == 0
+  env.close()
+
+
+def multigrid_amd_make(env_id):
+  import multigrid_amd
+  return multigrid_amd.make_batched(env_id, 256, seed=1)

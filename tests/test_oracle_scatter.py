@@ -209,3 +209,87 @@ def test_scatter_generator_statistics():
     assert tuple(g[sc[0][1], sc[0][0]]) == (8, 1, 0) and int((g[:, :, 0] == 2).sum()) == 28 + 6
     seen.add((int(sc[0][0]), int(sc[0][1])))
   assert len(seen) == 36
+
+
+def test_fixed_start_displacement_chain():
+  """EmptyEnv fixed start (empty.py:72-89), 8x8 with 3 agents starting on (1,1), (1,2), (1,3): agent 1 stands on agent
+  0's start cell and agent 2 on agent 1's when agent 0 finishes -> all three end on their own start cells facing east."""
+  from multigrid_amd import layouts
+  cells = layouts.empty_bordered(8, 8, goal=(6, 6))
+  env = c_oracle.OracleEnv(cells, W=8, H=8, A=3, V=5, max_steps=128, see_through=1,
+                           fixed_spawn=[(1, 1), (1, 2), (1, 3)], fixed_mode=c_oracle.FIXED_ALWAYS)
+  env.reset()
+  assert [tuple(p) for p in env.agent_pos] == [(1, 1), (1, 2), (1, 3)] and env.agent_dir == [0, 0, 0]
+  # walk agent 0 next to the goal: east x4 to (5,1), turn south, x5 to (5,6), turn east; meanwhile agents 1 and 2 go north
+  def step(a0, a1=6, a2=6):
+    return env.step([a0, a1, a2], order=[0, 1, 2])
+  for _ in range(4):
+    step(2)
+  step(1)
+  for _ in range(5):
+    step(2)
+  step(0)
+  assert tuple(env.agent_pos[0]) == (5, 6) and env.agent_dir[0] == 0
+  step(6, 0, 0)                       # agents 1 and 2 turn north (dir 3)
+  step(6, 2, 6)                       # agent 1 steps onto (1,1)
+  step(6, 6, 2)                       # agent 2 steps onto (1,2)
+  assert [tuple(p) for p in env.agent_pos] == [(5, 6), (1, 1), (1, 2)]
+  _, rew, done, _ = step(2)           # agent 0 reaches the goal: back to (1,1); 1 -> (1,2); 2 -> (1,3), all facing east
+  assert env.env_rewards[0] > 0
+  assert [tuple(p) for p in env.agent_pos] == [(1, 1), (1, 2), (1, 3)] and env.agent_dir == [0, 0, 0]
+  g = env.grid()
+  assert tuple(g[1, 1]) == (10, 0, 0) and tuple(g[2, 1]) == (10, 1, 0) and tuple(g[3, 1]) == (10, 2, 0)
+
+
+def test_fixed_start_cross():
+  """C oracle vs the Python restatements: EmptyEnv fixed start (no draws but the order) and a bitmap maze."""
+  rng = np.random.default_rng(5)
+  for size, A in ((5, 2), (8, 3)):
+    from multigrid_amd import layouts
+    cells = layouts.empty_bordered(size, size, goal=(size - 2, size - 2))
+    c = c_oracle.OracleEnv(cells, W=size, H=size, A=A, V=5, max_steps=2 * size * size, see_through=1, seed=size,
+                           fixed_spawn=[(1, 1 + i) for i in range(A)], fixed_mode=c_oracle.FIXED_ALWAYS)
+    feed = Feed()
+    c.reset()
+    py = py_ref_env.PyEmptyFixedEnv(size=size, n_agents=A, rand_int=feed.rand_int, order_fn=lambda: feed.order)
+    touches = 0
+    for t in range(1500):
+      acts = [int(v) for v in rng.choice(7, size=A, p=[.15, .15, .5, .05, .05, .05, .05])]
+      obs, rew, done, _ = c.step(acts)
+      order, _, _ = c.last_draws()
+      feed.order = [int(o) for o in order]
+      pobs, prew, pdone, _ = py.step(acts)
+      assert [float(r) for r in prew] == list(c.env_rewards) and bool(pdone) == done
+      assert np.array_equal(c.grid(), py_grid(py)), t
+      for a in range(A):
+        assert np.array_equal(obs['image'][a], pobs['image'][a])
+      touches += sum(1 for r in c.env_rewards if r > 0)
+      if done:
+        c.reset(); py.reset()
+    assert touches > 5
+  bitmap = np.array([[0, 0, 1, 0, 0, 0], [0, 1, 1, 0, 1, 0], [0, 0, 0, 0, 1, 0],
+                     [1, 1, 0, 1, 1, 0], [0, 0, 0, 0, 0, 0], [0, 1, 1, 1, 0, 0]])     # this test's own 6x6 maze
+  start, goal = (1, 1), (6, 6)
+  feed = Feed()
+  pyl = py_ref_env.PyBitmapMazeEnv(bitmap, start, goal, rand_int=lambda lo, hi: 0, order_fn=lambda: [0])
+  c = c_oracle.OracleEnv(pyl.layout, W=8, H=8, A=1, V=5, max_steps=128, see_through=1, seed=3, fixed_spawn=[start],
+                         fixed_mode=c_oracle.FIXED_AT_RESET)
+  c.reset()
+  _, _, spawn = c.last_draws()
+  assert tuple(spawn[0][:2]) == start
+  feed.q = [int(spawn[0][2])]
+  py = py_ref_env.PyBitmapMazeEnv(bitmap, start, goal, rand_int=feed.rand_int, order_fn=lambda: [0])
+  for t in range(1200):
+    acts = [int(rng.choice(7, p=[.2, .2, .5, .025, .025, .025, .025]))]
+    obs, rew, done, _ = c.step(acts)
+    _, respawn, _ = c.last_draws()
+    feed.q = [int(v) for v in respawn[0][:3]] if respawn[0][0] >= 0 else []
+    pobs, prew, pdone, _ = py.step(acts)
+    assert [float(r) for r in prew] == list(c.env_rewards) and bool(pdone) == done
+    assert np.array_equal(obs['image'][0], pobs['image'][0]), t
+    if done:
+      c.reset()
+      _, _, spawn = c.last_draws()
+      assert tuple(spawn[0][:2]) == start
+      feed.q = [int(spawn[0][2])]
+      py.reset()
