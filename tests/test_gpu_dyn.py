@@ -238,3 +238,32 @@ def test_doorkey_registry_and_refcompat():
     oobs, orew, odone, _ = orc.step(act)
     assert list(rew) == list(orew) and done == odone
   env.close()
+
+
+@pytest.mark.parametrize('env_id', ['MultiGrid-DoorKey-8x8-v0', 'MultiGrid-Meetup-Random-8x8-v0', 'MultiGrid-Cluttered-v0',
+                                    'MultiGrid-FourRooms-15x15-v0'])
+def test_sharding_invariance_of_generated_kinds(env_id):
+  """Philox streams are keyed by the global env id: two shards (env_id_base 0 and 320) produce exactly the buffers of
+  one handle holding all 640 envs — layouts, spawns, orders, respawns, rewards — for every generated kind."""
+  _need_gpu()
+  import multigrid_amd
+  whole = multigrid_amd.make_batched(env_id, 640, seed=11, max_steps=40)
+  parts = [multigrid_amd.make_batched(env_id, 320, seed=11, max_steps=40, env_id_base=b) for b in (0, 320)]
+  for e in [whole] + parts:
+    e.reset()
+  for t in range(90):
+    for e in [whole] + parts:
+      e.step_random()
+  for k, part in enumerate(parts):
+    sl = slice(320 * k, 320 * (k + 1))
+    assert torch.equal(whole.env_state[sl], part.env_state)
+    assert torch.equal(whole.reward[:, sl], part.reward)
+    assert torch.equal(whole.done[sl], part.done)
+    assert torch.equal(whole.grid_kinds()[sl], part.grid_kinds())
+    assert torch.equal(whole.carry[sl], part.carry)
+    if whole.obs_full is not None:
+      assert torch.equal(whole.obs_full[sl], part.obs_full)
+    else:
+      assert torch.equal(whole.obs_image[:, sl], part.obs_image)
+  for e in [whole] + parts:
+    e.close()
