@@ -48,6 +48,7 @@ extern "C" {
 /* shaping_kind */
 #define MG_SHAPING_NONE 0   /* reward = env reward (multigrid.py:881-883) */
 #define MG_SHAPING_V8   1   /* reward = v8_robust_ppo.py:171-220 shaped reward */
+#define MG_SHAPING_V7   2   /* reward = v7_stable_goal_focused_ppo.py:60-108 shaped reward (StableRewardShaper) */
 
 /* kernel_path: how the static part of an agent's view is produced.  TABLE = precomputed once
  * per (free cell, dir) on the host and kept in LDS; GENERIC = slice/rotate/process_vis evaluated

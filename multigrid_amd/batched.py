@@ -57,7 +57,7 @@ class BatchedMultiGrid:
     cfg = _lib.MgConfig(
         width=self.width, height=self.height, n_agents=n_agents, view_size=view_size, max_steps=max_steps,
         see_through_walls=int(see_through_walls), competitive=int(competitive),
-        shaping_kind={None: 0, 'none': 0, 'v8': 1}[shaping], auto_reset=int(auto_reset),
+        shaping_kind={None: 0, 'none': 0, 'v8': 1, 'v7': 2}[shaping], auto_reset=int(auto_reset),
         env_kind=_lib.KINDS[kind], emit_env_reward=int(emit_env_reward),
         gen_n_goals=int(n_goals), gen_n_clutter=int(n_clutter), gen_flags=_lib.GEN_LAVA if walls_are_lava else 0,
         kernel_path={'auto': 0, 'generic': 1, 'table': 2}[kernel_path],

@@ -456,7 +456,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 #pragma unroll
     for (int a = 0; a < A; ++a) {
       out_rew[a] = rew[a];
-      if (p.shaping == MG_SHAPING_V8) {
+      if (p.shaping != MG_SHAPING_NONE) {
         // get_goal_position (v8:159-169): the per-env scattered goal of a Cluttered layout, else the handle's
         const bool own = (p.kind == MG_KIND_CLUTTERED && p.n_goals != 0) || p.kind == MG_KIND_FOURROOMS;
         const int gx = own ? (int)(goal[0] & 63u) : p.gx, gy = own ? (int)((goal[0] >> 6) & 63u) : p.gy;

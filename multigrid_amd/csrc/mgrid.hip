@@ -448,18 +448,21 @@ __device__ __forceinline__ uint32_t agent_order(const Params& p, int64_t n, uint
   return ordw;
 }
 
-// v8 shape_rewards for one agent (v8_robust_ppo.py:171-220), float64, one rounding per
-// operation.  w = the agent's shaper bits (prev_x, prev_y, valid, stationary), me = its post-step
-// position word, env_rew = its env reward.  Returns the new shaper bits.
+// shape_rewards for one agent, float64, one rounding per operation: the v8 shaper (v8_robust_ppo.py:171-220) or, with
+// shaping == MG_SHAPING_V7, the v7 one (v7_stable_goal_focused_ppo.py:60-108; same structure, other constants, and a
+// goal touch leaves prev_* and the count as they were, v7:70-72, where v8 clears them, v8:181-186).
+// w = the agent's shaper bits (prev_x, prev_y, valid, stationary), me = its post-step position word, env_rew = its
+// env reward.  Returns the new shaper bits.
 // REL = false: dist[y*W + x] = distance of cell (x, y) to the handle's one goal (shared-map kernels);
 // REL = true: dist[|dy|*LW + |dx|] = sqrt(dx^2 + dy^2), looked up relative to goal (gx, gy), which may
 // differ per env (mutable-grid kernel).  Both tables are built on the host with the same sqrt.
 template <bool REL = false>
 __device__ __forceinline__ uint32_t v8_shape(const Params& p, const double* dist, uint32_t w, uint32_t me, uint32_t act,
                                              double env_rew, double& out, int gx = 0, int gy = 0) {
-  if (env_rew > 0.0) {                            // goal touch: prev_* cleared, count 0 (v8:181-186)
-    out = 5.0;
-    return 0u;
+  const bool v7 = p.shaping == MG_SHAPING_V7;
+  if (env_rew > 0.0) {                            // goal touch: prev_* cleared, count 0 (v8:181-186); kept (v7:70-72)
+    out = v7 ? 10.0 : 5.0;
+    return v7 ? (w & ~AW_POSDIR) : 0u;
   }
   const int x = aw_x(me), y = aw_y(me);
   double r = 0.0;
@@ -470,20 +473,23 @@ __device__ __forceinline__ uint32_t v8_shape(const Params& p, const double* dist
   if (has) {
     const int qx = min(px, p.W - 1), qy = min(py, p.H - 1);
     const double prev = REL ? dist[abs(qy - gy) * p.LW + abs(qx - gx)] : dist[qy * p.W + qx];
-    r = r + (prev - cur) * 0.2;                   // v8:193-195
-    if (px == x && py == y) {                     // v8:199-206
-      stat = min(stat + 1u, 7u);                  // only "> 3" is ever tested: saturating is exact
-      if (stat > 3u) r = r - 0.05;
+    r = r + (prev - cur) * 0.2;                   // v8:193-195, v7:79-81
+    if (px == x && py == y) {                     // v8:199-206, v7:85-93
+      stat = min(stat + 1u, 7u);                  // v8 tests "> 3" only; v7 also takes min(0.05, count * 0.01), which is
+      if (stat > 3u) {                            // 0.05 from count 5 on: saturating at 7 is exact for both
+        const double pen = (double)stat * 0.01;
+        r = r - ((v7 && pen < 0.05) ? pen : 0.05);
+      }
     } else {
       stat = 0u;
-      r = r + 0.02;
+      r = r + (v7 ? 0.01 : 0.02);
     }
   }
-  if (act == 2u) r = r + 0.02;                    // v8:209-212
-  else if (act <= 1u) r = r + 0.01;
-  if (-0.2 > r) r = -0.2;                         // max(reward, -0.2), v8:215
+  if (act == 2u) r = r + 0.02;                    // v8:209-212, v7:96-99
+  else if (act <= 1u) r = r + (v7 ? 0.005 : 0.01);
+  if (-0.2 > r) r = -0.2;                         // max(reward, -0.2), v8:215, v7:104
   out = r;
-  return ((uint32_t)x << 14) | ((uint32_t)y << 20) | (1u << 26) | (stat << 27);   // v8:218
+  return ((uint32_t)x << 14) | ((uint32_t)y << 20) | (1u << 26) | (stat << 27);   // v8:218, v7:82,106
 }
 
 // EmptyEnv.place_one_agent with agent_start='fixed' (multigrid_envs/empty.py:72-104): agent a goes to its start cell
@@ -598,7 +604,7 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
     for (int a = 0; a < A; ++a) {
       rew[a] = ((gbits >> a) & 1u) ? rgoal : 0.0;
       out_rew[a] = rew[a];
-      if (p.shaping == MG_SHAPING_V8 && MG_ABL != 4)
+      if (p.shaping != MG_SHAPING_NONE && MG_ABL != 4)
         shw[a] = v8_shape(p, dist, shw[a], pd_get(pd, a), (actw >> (3 * a)) & 7u, rew[a], out_rew[a]);
     }
 
@@ -1060,7 +1066,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (c.width < 3 || c.height < 3 || c.width > 64 || c.height > 64) return fail(MG_EINVAL, "width/height must be in [3,64]");
   if (c.n_envs < 1) return fail(MG_EINVAL, "n_envs must be >= 1");
   if (c.max_steps < 1 || c.max_steps > 65534) return fail(MG_EINVAL, "max_steps must be in [1,65534]");
-  if (c.shaping_kind != MG_SHAPING_NONE && c.shaping_kind != MG_SHAPING_V8) return fail(MG_EINVAL, "unknown shaping_kind");
+  if (c.shaping_kind < MG_SHAPING_NONE || c.shaping_kind > MG_SHAPING_V7) return fail(MG_EINVAL, "unknown shaping_kind");
   if (c.kernel_path < MG_PATH_AUTO || c.kernel_path > MG_PATH_TABLE) return fail(MG_EINVAL, "unknown kernel_path");
   if (c.env_id_base < 0 || (uint64_t)c.env_id_base + (uint64_t)c.n_envs > 0xFFFFFFFFull)
     return fail(MG_EINVAL, "global env ids must fit 32 bits");

@@ -722,6 +722,45 @@ static void shape_rewards(mgo_env* e, const double* orig, const int* actions, do
   }
 }
 
+/* StableRewardShaper.shape_rewards (v7_stable_goal_focused_ppo.py:60-108), float64 with one rounding per
+ * Python operation.  Unlike v8, a goal touch `continue`s past every prev_* update (v7:70-72), so the
+ * shaper keeps what it held; the caller clears it at env.reset() only (v7:291,338). */
+static void shape_rewards_v7(mgo_env* e, const double* orig, const int* actions, double* shaped) {
+  int gx, gy;
+  goal_position(e, &gx, &gy);                            /* v7:47-58, same search and (13,13) default as v8 */
+  for (int i = 0; i < e->A; ++i) {
+    int px = e->ax[i], py = e->ay[i], action = actions[i];
+    if (orig[i] > 0) { shaped[i] = 10.0; continue; }     /* v7:70-72 */
+    volatile double reward = 0.0;                        /* v7:75 */
+    long dx = px - gx, dy = py - gy;
+    double current_dist = sqrt((double)(dx * dx + dy * dy));   /* v7:78 */
+    if (e->sh_has[i]) {                                  /* v7:79-81 */
+      volatile double dist_change = e->sh_dist[i] - current_dist;
+      volatile double term = dist_change * 0.2;
+      reward = reward + term;
+    }
+    e->sh_dist[i] = current_dist;                        /* v7:82 */
+    if (e->sh_has[i]) {                                  /* v7:85-93 (prev_positions set iff prev_distances set) */
+      if (px == e->sh_px[i] && py == e->sh_py[i]) {
+        e->sh_stat[i] += 1;
+        if (e->sh_stat[i] > 3) {                         /* min(0.05, count * 0.01) */
+          volatile double pen = (double)e->sh_stat[i] * 0.01;
+          reward = reward - (pen < 0.05 ? pen : 0.05);
+        }
+      } else {
+        e->sh_stat[i] = 0;
+        reward = reward + 0.01;
+      }
+    }
+    if (action == 2) reward = reward + 0.02;             /* v7:96-99 */
+    else if (action == 0 || action == 1) reward = reward + 0.005;
+    double r = reward;
+    if (-0.2 > r) r = -0.2;                              /* max(shaped, -0.2), v7:104 */
+    shaped[i] = r;
+    e->sh_px[i] = px; e->sh_py[i] = py; e->sh_has[i] = 1; /* v7:106 */
+  }
+}
+
 /* MultiGridEnv.step (multigrid.py:963-995) followed by the v8 shaper (v8:239-243) and the
  * build's auto-reset.  order == NULL -> Philox Fisher-Yates; respawn/reset_spawn == NULL ->
  * Philox rejection sampling.  t = step index (Philox counter).  Outputs may be NULL. */
@@ -788,6 +827,7 @@ void mgo_step_ex(mgo_env* e, const int* actions, const uint8_t* order, const int
 
   double shaped[MAXA];
   if (e->shaping == 1) shape_rewards(e, rewards, actions, shaped);
+  else if (e->shaping == 2) shape_rewards_v7(e, rewards, actions, shaped);
   else for (int a = 0; a < A; ++a) shaped[a] = rewards[a];
 
   if (collective_done && e->auto_reset) { e->inj_gen = reset_gen; do_reset(e, reset_spawn, t); e->inj_gen = NULL; }

@@ -715,6 +715,45 @@ class V8Shaper:
     return out
 
 
+class V7Shaper(V8Shaper):
+  """StableRewardShaper, v7_stable_goal_focused_ppo.py:35-108: the v8 shaper's predecessor.  Same state and goal
+  search (v7:47-58); a goal touch pays 10.0 and leaves the state as it is (v7:70-72), standing still costs
+  min(0.05, count * 0.01) from the fourth step on (v7:89-90), moving earns 0.01 (v7:93), turning 0.005 (v7:98-99)."""
+
+  def shape(self, agent_positions, original_rewards, actions):
+    out = list(original_rewards)
+    goal = self.goal_position()
+    for i in range(self.env.n_agents):
+      pos = np.array(agent_positions[i])
+      action = actions[i]
+      if original_rewards[i] > 0:
+        out[i] = 10.0
+        continue
+      out[i] = 0.0
+      dist = np.linalg.norm(pos - goal)
+      if self.prev_distances[i] is not None:
+        out[i] += (self.prev_distances[i] - dist) * 0.2
+      self.prev_distances[i] = dist
+      if self.prev_positions[i] is not None:
+        if np.array_equal(pos, self.prev_positions[i]):
+          self.stationary_count[i] += 1
+          if self.stationary_count[i] > 3:
+            out[i] -= min(0.05, self.stationary_count[i] * 0.01)
+        else:
+          self.stationary_count[i] = 0
+          out[i] += 0.01
+      if action == 2:
+        out[i] += 0.02
+      elif action in [0, 1]:
+        out[i] += 0.005
+      out[i] = max(out[i], -0.2)
+      self.prev_positions[i] = pos.copy()
+    return out
+
+
+SHAPERS = {1: V8Shaper, 2: V7Shaper}
+
+
 def random_rollout_rate(cells, seconds=5.0, seed=0, shaping=True):
   """env-only random-action rollout; returns (agent_steps, wall_seconds).  cpu_baseline leg."""
   import time

@@ -60,7 +60,7 @@ class PyReplay:
   def __init__(self, cells, spawn, A=3, V=5, max_steps=100, shaping=0, **kw):
     self.env = InjectedPyEnv(cells, spawn, n_agents=A, view_size=V, max_steps=max_steps, **kw)
     self.env._spawn = None
-    self.shaper = py_ref_env.V8Shaper(self.env) if shaping else None
+    self.shaper = py_ref_env.SHAPERS[shaping](self.env) if shaping else None
     self.A = A
 
   def obs(self):

@@ -39,7 +39,7 @@ def _doorkey(size, A, n, max_steps, seed, shaping='v8', **kw):
   from multigrid_amd.batched import BatchedMultiGrid
   env = BatchedMultiGrid(None, n_envs=n, kind='doorkey', size=size, n_agents=A, view_size=7, max_steps=max_steps,
                          shaping=shaping, seed=seed, emit_env_reward=True, **kw)
-  orc = c_oracle.OracleBatch(None, n, W=size, H=size, A=A, V=7, max_steps=max_steps, shaping=1 if shaping == 'v8' else 0,
+  orc = c_oracle.OracleBatch(None, n, W=size, H=size, A=A, V=7, max_steps=max_steps, shaping={'v8': 1, 'v7': 2, None: 0}[shaping],
                              auto_reset=int(kw.get('auto_reset', True)), competitive=int(kw.get('competitive', False)),
                              seed=seed, gid_base=kw.get('env_id_base', 0), kind='doorkey')
   return env, orc
@@ -81,6 +81,26 @@ def test_doorkey_free_running_parity(size, A, n, steps, max_steps):
     assert tot['pickup'] > 0 and tot['open_doors'] > 0, tot
   if size == 5:
     assert tot['goal'] > 0 and tot['no_door'] > 0, tot
+  env.close()
+
+
+def test_doorkey_v7_shaper_parity():
+  """shaping='v7' (v7_stable_goal_focused_ppo.py:60-108) on per-env mutable grids: DoorKey-5x5, where random walks do
+  reach the goal, so the touch branch (10.0, shaper state kept) runs"""
+  _need_gpu()
+  n = 2000
+  env, orc = _doorkey(5, 1, n, 60, seed=71, shaping='v7')
+  env.reset()
+  orc.reset()
+  touches = tens = 0
+  for t in range(220):
+    env.step_random()
+    orc.step()
+    _cmp(env, orc, 'v7 step %d' % t)
+    touches += int((orc.env_reward[:, :n] > 0).sum())
+    tens += int((orc.reward[:, :n] == 10.0).sum())
+  assert env.check_errors() == 0 and orc.errors() == 0
+  assert touches > 0 and tens == touches
   env.close()
 
 

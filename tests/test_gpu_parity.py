@@ -45,7 +45,7 @@ def _make(cells, n, **kw):
   okw_skip = kw.pop('kernel_path')
   okw = dict(W=W, H=H, A=kw.get('n_agents', 3), V=kw.get('view_size', 5), max_steps=kw.get('max_steps', 100),
              see_through=int(kw.get('see_through_walls', False)), competitive=int(kw.get('competitive', False)),
-             shaping=1 if kw.get('shaping', 'v8') == 'v8' else 0, auto_reset=int(kw.get('auto_reset', True)),
+             shaping={'v8': 1, 'v7': 2, None: 0}[kw.get('shaping', 'v8')], auto_reset=int(kw.get('auto_reset', True)),
              seed=kw.get('seed', 0), gid_base=kw.get('env_id_base', 0))
   env = BatchedMultiGrid(cells, n_envs=n, emit_env_reward=True, kernel_path=okw_skip, **kw)
   orc = c_oracle.OracleBatch(cells, n, **okw)
@@ -86,6 +86,37 @@ def test_free_running_philox_parity(cluttered_cells, n, steps, seed):
   assert env.check_errors() == 0 and orc.errors() == 0
   if n >= 1000:
     assert touches > 0   # the rare branch (goal touch + respawn) was exercised
+
+
+@pytest.mark.parametrize('fast', [False, True])
+def test_v7_shaper_parity(cluttered_cells, fast):
+  """shaping='v7' (StableRewardShaper, v7_stable_goal_focused_ppo.py:60-108) on the shared-map kernels, free-running
+  with auto-reset; the goal-touch branch, which keeps the shaper state where v8 clears it, must have run."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  n = 3000
+  if fast:
+    env = BatchedMultiGrid(cluttered_cells, n_envs=n, seed=21, shaping='v7')
+    orc = c_oracle.OracleBatch(cluttered_cells, n, shaping=2, auto_reset=1, seed=21)
+  else:
+    env, orc = _make(cluttered_cells, n, seed=21, shaping='v7')
+  rng = np.random.RandomState(21)
+  env.reset()
+  orc.reset()
+  touches, tens, capped = 0, 0, 0
+  for t in range(210):
+    act = rng.randint(0, 7, size=(3, orc.stride)).astype(np.uint8)
+    act[rng.rand(3, orc.stride) < 0.35] = 2
+    act[:, : n // 4] = np.where(rng.rand(3, n // 4) < 0.9, 6, act[:, : n // 4])   # idlers: the stationary cap
+    env.step(torch.from_numpy(act).to(env.device))
+    orc.step(act)
+    _cmp_step(env, orc, 'v7 step %d' % t)
+    touches += int((orc.env_reward[:, :n] > 0).sum())
+    tens += int((orc.reward[:, :n] == 10.0).sum())
+    capped += int((orc.reward[:, :n] == -0.05).sum()) + int((orc.reward[:, :n] == -0.04).sum())
+  assert env.check_errors() == 0 and orc.errors() == 0
+  assert touches > 0 and tens == touches and capped > 0
+  env.close()
 
 
 @pytest.mark.parametrize('path,n,grid,nw', [('table', 3000, None, None),      # all inputs fetched up front

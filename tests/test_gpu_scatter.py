@@ -23,7 +23,7 @@ def _make(kind, size, A, n, max_steps, seed, V=5, shaping='v8', **gen):
                          shaping=shaping, seed=seed, emit_env_reward=True, n_goals=gen['n_goals'],
                          n_clutter=gen['n_clutter'], walls_are_lava=gen.get('lava', False),
                          auto_reset=gen.get('auto_reset', True))
-  orc = c_oracle.OracleBatch(None, n, W=size, H=size, A=A, V=V, max_steps=max_steps, shaping=1 if shaping == 'v8' else 0,
+  orc = c_oracle.OracleBatch(None, n, W=size, H=size, A=A, V=V, max_steps=max_steps, shaping={'v8': 1, 'v7': 2, None: 0}[shaping],
                              auto_reset=int(gen.get('auto_reset', True)), seed=seed, kind=kind, n_goals=gen['n_goals'],
                              n_clutter=gen['n_clutter'], lava=gen.get('lava', False))
   return env, orc
@@ -130,6 +130,27 @@ def test_fourrooms_parity(size, A, V, n, steps):
   assert np.array_equal(env2.agent_state.cpu().numpy().view(np.uint32), orc.agent_state()[:, :n])
   assert np.array_equal(env2.obs_image.cpu().numpy().reshape(A, n, -1), orc.obs_image[:, :n])
   env.close(); env2.close()
+
+
+@pytest.mark.parametrize('kind,size,A,V', [('cluttered', 8, 3, 5), ('fourrooms', 9, 2, 5)])
+def test_v7_shaper_on_the_mutable_grid_kernel(kind, size, A, V):
+  """shaping='v7' where the goal differs per env (the relative distance table)"""
+  _need_gpu()
+  n = 3000
+  env, orc = _make(kind, size, A, n, 60, seed=44, V=V, shaping='v7', n_goals=1 if kind == 'cluttered' else 0,
+                   n_clutter=4 if kind == 'cluttered' else 0)
+  env.reset()
+  orc.reset()
+  touches = tens = 0
+  for t in range(200):
+    env.step_random()
+    orc.step()
+    _cmp(env, orc, 'v7 %s step %d' % (kind, t))
+    touches += int((orc.env_reward[:, :n] > 0).sum())
+    tens += int((orc.reward[:, :n] == 10.0).sum())
+  assert env.check_errors() == 0 and orc.errors() == 0
+  assert touches > 0 and tens == touches
+  env.close()
 
 
 def test_scatter_injection_and_errors():
