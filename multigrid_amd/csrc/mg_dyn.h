@@ -22,7 +22,7 @@
 constexpr uint32_t F_OVERLAP = 1u << 28;   // can_overlap(): floor, open door (goal/lava are F_KILL)
 constexpr uint32_t F_PICKUP = 1u << 29;    // can_pickup(): key, ball, box
 constexpr uint32_t F_DOOR = 1u << 30;
-constexpr uint32_t F_BOX = 1u << 31;
+constexpr uint32_t F_BOX = 1u << 24;
 constexpr uint32_t K_WALL = MG_T_WALL * 8 + 5;                 // grey wall: wall_rect and Grid.slice's padding
 constexpr uint32_t K_GOAL = MG_T_GOAL * 8 + 1;                 // green goal
 constexpr uint32_t K_DOOR_YELLOW_LOCKED = 128 + 4 * 4 + 2;     // Door('yellow', is_locked=True), doorkey.py:60
@@ -68,7 +68,8 @@ constexpr int kPreMax = 16;   // grid dwords per lane fetched per batch when a g
 // PRE (template parameter of the kernels) = grid dwords per lane prefetched in registers: 16 covers grids up to 64
 // cells; the view-5 and the fully observed instantiations also exist with 64 (grids up to 16x16 — they have the
 // registers for it at two waves per SIMD), picked at mg_create for grids that need it.
-__device__ __forceinline__ int g_off(const Params& p, int x, int y) { return ((y + 1) * (p.W + 2) + x + 1) * kCellB; }
+// (24-bit multiplies: full rate, where the 32-bit ones issue at a quarter of it; every factor here is below 2^13)
+__device__ __forceinline__ int g_off(const Params& p, int x, int y) { return __mul24(__mul24(y + 1, p.W + 2) + x + 1, kCellB); }
 __device__ __forceinline__ uint32_t g_get(const uint8_t* gl, int off) { return gl[off]; }
 __device__ __forceinline__ void g_set(uint8_t* gl, int off, uint32_t k) { gl[off] = (uint8_t)k; }
 
@@ -128,27 +129,27 @@ __device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, cons
   const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
   const int rx = -fy, ry = fx;
   const int x0 = x + fx * (V - 1) - rx * (V / 2), y0 = y + fy * (V - 1) - ry * (V / 2);   // view cell (0,0)
-  const int PW = p.W + 2;
+  const int PWB = __mul24(p.W + 2, kCellB);
   const int cx0 = min(max(x0, -1), p.W), cy0 = min(max(y0, -1), p.H);
   int U[V], Vv[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) {
     const int ux = min(max(x0 + i * rx, -1), p.W) - cx0, uy = min(max(y0 + i * ry, -1), p.H) - cy0;
     const int wx = min(max(x0 - i * fx, -1), p.W) + 1, wy = min(max(y0 - i * fy, -1), p.H) + 1;
-    U[i] = (uy * PW + ux) * kCellB;
-    Vv[i] = (wy * PW + wx) * kCellB;
+    U[i] = __mul24(uy, PWB) + __mul24(ux, kCellB);
+    Vv[i] = __mul24(wy, PWB) + __mul24(wx, kCellB);
   }
   uint32_t code[V * V];
   uint32_t opq[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) opq[j] = 0;
 #pragma unroll
-  for (int vx = 0; vx < V; ++vx)
+  for (int vx = V - 1; vx >= 0; --vx)
 #pragma unroll
     for (int vy = 0; vy < V; ++vy) {
       const uint32_t w = lut[g_get(g, U[vx] + Vv[vy])];
-      code[vx * V + vy] = w & 0xFFFFFFu;
-      opq[vy] |= ((w >> 24) & 1u) << vx;
+      code[vx * V + vy] = w;
+      opq[vy] = view_row_bit(opq[vy], w);
     }
   pack_view<V>(code, opq, p.see_through != 0, lut[ck] & 0xFFFFFFu, s, vm);
 }

@@ -9,6 +9,13 @@
 // Per row: the incoming mask floods left and right through transparent cells (a visible
 // transparent cell makes both horizontal neighbours visible); every visible transparent cell
 // then makes the three cells above it visible.
+//
+// The flood is evaluated in closed form with a carry chain instead of V-1 shift-and-or rounds: with
+// t = transparent cells of the row and s = m & t the visible transparent ones, t + s carries from
+// each seed through the rest of its run of ones and leaves a one in the cell that ends the run, so
+// (t + s) ^ t = every cell from the lowest seed of a run up to and including the first cell past the
+// run, except seeds above the lowest one (their bit is 1 + 1 + carry = 1, unchanged) — and those are
+// in m already.  The flood towards lower columns is the same on the bit-reversed row.
 #pragma once
 #include <stdint.h>
 
@@ -27,13 +34,11 @@ MG_HD void mg_vis_rows(const uint32_t (&opq)[V], uint32_t (&vis)[V]) {
   vis[V - 1] = 1u << (V / 2);
 #pragma unroll
   for (int j = V - 1; j >= 0; --j) {
-    uint32_t m = vis[j];
     const uint32_t t = ~opq[j] & full;
-#pragma unroll
-    for (int it = 0; it < V - 1; ++it) {
-      const uint32_t T = m & t;
-      m |= ((T << 1) | (T >> 1)) & full;
-    }
+    const uint32_t s = vis[j] & t;
+    const uint32_t tr = __builtin_bitreverse32(t), sr = __builtin_bitreverse32(s);
+    const uint32_t up = (t + s) ^ t, down = __builtin_bitreverse32((tr + sr) ^ tr);
+    const uint32_t m = (vis[j] | up | down) & full;
     vis[j] = m;
     if (j > 0) {
       const uint32_t T = m & t;

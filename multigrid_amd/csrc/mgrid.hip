@@ -45,7 +45,7 @@ enum { P_ORDER = 0, P_RESPAWN = 1, P_SPAWN = 2, P_ACTION = 3 };
 enum { OP_STEP = 0, OP_RESET = 1 };
 
 // map cell word: type | color<<8 | state<<16 | flags<<24
-constexpr uint32_t F_OPAQUE = 1u << 24;  // !see_behind()
+constexpr uint32_t F_OPAQUE = 1u << 31;  // !see_behind(); the top bit, so one v_alignbit shifts it into a row mask (view_row_bit)
 constexpr uint32_t F_FREE = 1u << 25;    // grid.get(...) is None
 constexpr uint32_t F_KILL = 1u << 26;    // goal or lava: agent_is_done
 constexpr uint32_t F_GOAL = 1u << 27;
@@ -193,14 +193,22 @@ __device__ __forceinline__ uint32_t place_agent(const Params& p, const uint32_t*
 // part of a view (cell codes with visibility applied, own cell = empty) depends only on
 // (pos, dir): `static_view` computes it from the map; on the table path it was computed once on
 // the host for every (free cell, dir) and is simply fetched from LDS.
-// Output: s[0..NW-1] = the V*V 3-byte codes as a dword stream, vm = visibility bits (vx*V+vy).
+// Output: s[0..NW-1] = the V*V 3-byte codes as a dword stream, vm = visibility bits (vy*V+vx).
 // ---------------------------------------------------------------------------------------------
-// process_vis + own cell + encode: from the V*V cell codes (code[vx*V+vy] = type | color<<8 |
-// state<<16) and the per-row opacity bits (opq[vy] bit vx) to the dword stream and visibility mask.
+// One more cell of a view row: the opacity bits of row vy are collected by walking vx from V-1 down to 0, each step
+// shifting the row mask left and taking the cell's F_OPAQUE (bit 31) as the new bit 0 — a single v_alignbit_b32.
+__device__ __forceinline__ uint32_t view_row_bit(uint32_t row, uint32_t cell_word) {
+  return __builtin_amdgcn_alignbit(row, cell_word, 31);
+}
+
+// process_vis + own cell + encode: from the V*V cell words (w[vx*V+vy]: type | color<<8 | state<<16 in the low three
+// bytes, the top byte is ignored) and the per-row opacity bits (opq[vy] bit vx) to the dword stream
+// and the visibility mask vm (bit vy*V + vx).  Four 3-byte codes make three dwords, one v_perm_b32 each.
 template <int V>
-__device__ __forceinline__ void pack_view(uint32_t (&code)[V * V], const uint32_t (&opq)[V], bool see_through,
+__device__ __forceinline__ void pack_view(uint32_t (&w)[V * V], const uint32_t (&opq)[V], bool see_through,
                                           uint32_t own_code, uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t& vm) {
-  constexpr int NW = ViewGeom<V>::NW;
+  constexpr int NW = ViewGeom<V>::NW, NC = V * V;
+  static_assert(NC % 4 == 1 && NW == (NC / 4) * 3 + 1, "groups of four cells, then the last cell alone");
   uint32_t vis[V];
   if (see_through) {
 #pragma unroll
@@ -208,22 +216,24 @@ __device__ __forceinline__ void pack_view(uint32_t (&code)[V * V], const uint32_
   } else {
     mg_vis_rows<V>(opq, vis);
   }
-  code[(V / 2) * V + (V - 1)] = own_code;
-#pragma unroll
-  for (int i = 0; i <= NW; ++i) s[i] = 0;
+  w[(V / 2) * V + (V - 1)] = own_code;
   vm = 0;
 #pragma unroll
-  for (int vx = 0; vx < V; ++vx)
+  for (int j = 0; j < V; ++j) vm |= (uint64_t)vis[j] << (j * V);
 #pragma unroll
-    for (int vy = 0; vy < V; ++vy) {
-      const int c = vx * V + vy;
-      const uint32_t seen = (vis[vy] >> vx) & 1u;
-      const uint32_t v = seen ? code[c] : 0u;                     // unseen -> (0,0,0)
-      vm |= (uint64_t)seen << c;
-      const int b = 3 * c, wi = b >> 2, sh = (b & 3) * 8;
-      s[wi] |= v << sh;
-      if (sh > 8) s[wi + 1] |= v >> (32 - sh);
-    }
+  for (int c = 0; c < NC; ++c) {                                 // unseen -> (0,0,0)
+    const int vx = c / V, vy = c % V;
+    w[c] &= (uint32_t)__builtin_amdgcn_sbfe((int)vis[vy], vx, 1);
+  }
+#pragma unroll
+  for (int q = 0; q < NC / 4; ++q) {
+    const uint32_t c0 = w[4 * q], c1 = w[4 * q + 1], c2 = w[4 * q + 2], c3 = w[4 * q + 3];
+    s[3 * q] = __builtin_amdgcn_perm(c1, c0, 0x04020100u);       // c0.0 c0.1 c0.2 c1.0
+    s[3 * q + 1] = __builtin_amdgcn_perm(c2, c1, 0x05040201u);   // c1.1 c1.2 c2.0 c2.1
+    s[3 * q + 2] = __builtin_amdgcn_perm(c3, c2, 0x06050402u);   // c2.2 c3.0 c3.1 c3.2
+  }
+  s[NW - 1] = w[NC - 1] & 0xFFFFFFu;
+  s[NW] = 0;
 }
 
 template <int V>
@@ -241,12 +251,12 @@ __device__ __forceinline__ void static_view(const Params& p, const uint32_t* map
 #pragma unroll
   for (int j = 0; j < V; ++j) opq[j] = 0;
 #pragma unroll
-  for (int vx = 0; vx < V; ++vx)
+  for (int vx = V - 1; vx >= 0; --vx)
 #pragma unroll
     for (int vy = 0; vy < V; ++vy) {
       const uint32_t w = map[i0 + vx * dr - vy * df];
-      code[vx * V + vy] = w & 0xFFFFFFu;
-      opq[vy] |= ((w >> 24) & 1u) << vx;
+      code[vx * V + vy] = w;
+      opq[vy] = view_row_bit(opq[vy], w);
     }
   // own cell <- carried object or None, after process_vis (multigrid.py:1029-1033); nothing can
   // be carried on a static map
@@ -306,9 +316,8 @@ __device__ __forceinline__ void emit_obs(uint64_t pd, int a, uint32_t (&s)[ViewG
     const int along = ox * fx + oy * fy, side = ox * rx + oy * ry;
     const int vy = V - 1 - along, vx = side + V / 2;
     if ((unsigned)vx < (unsigned)V && (unsigned)vy < (unsigned)V) {
-      const int c = vx * V + vy;
-      if ((vm >> c) & 1u) {
-        uint8_t* q = sb + c * 3;
+      if ((vm >> (vy * V + vx)) & 1u) {
+        uint8_t* q = sb + (vx * V + vy) * 3;
         q[0] = (uint8_t)MG_T_AGENT;
         q[1] = (uint8_t)b;
         q[2] = (uint8_t)(((uint32_t)aw_d(o) - (uint32_t)d - 1u) & 3u);
@@ -809,7 +818,7 @@ void host_view_entry(const std::vector<uint32_t>& map, int PW, int pad, bool see
       const int wx = x + fx * (V - 1 - vy) + rx * (vx - V / 2), wy = y + fy * (V - 1 - vy) + ry * (vx - V / 2);
       const uint32_t w = map[(size_t)(wy + pad) * PW + (wx + pad)];
       code[vx * V + vy] = w & 0xFFFFFFu;
-      opq[vy] |= ((w >> 24) & 1u) << vx;
+      opq[vy] |= (w >> 31) << vx;
     }
   if (see_through) for (int j = 0; j < V; ++j) vis[j] = (1u << V) - 1u;
   else mg_vis_rows<V>(opq, vis);
@@ -821,7 +830,7 @@ void host_view_entry(const std::vector<uint32_t>& map, int PW, int pad, bool see
     for (int vy = 0; vy < V; ++vy) {
       const int c = vx * V + vy;
       const uint32_t seen = (vis[vy] >> vx) & 1u, v = seen ? code[c] : 0u;
-      vm |= seen << c;
+      vm |= seen << (vy * V + vx);
       bytes[3 * c] = (uint8_t)v; bytes[3 * c + 1] = (uint8_t)(v >> 8); bytes[3 * c + 2] = (uint8_t)(v >> 16);
     }
   static_assert(ROWB <= NW * 4, "");
