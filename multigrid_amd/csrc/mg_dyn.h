@@ -62,6 +62,9 @@ __host__ __device__ inline uint32_t kind_word(uint32_t k) {
 
 // LDS grid of one wave: cell (x, y), x in [-1, W], y in [-1, H] (the ring holds grey walls), lane l
 // at byte ((y+1)*(W+2) + x+1)*kCellB + l.  gl = the wave's grid base + lane.
+#ifndef MG_VIEW_PHASES
+#define MG_VIEW_PHASES 1
+#endif
 constexpr int kCellB = 68;    // bytes per cell row: 64 lanes + 4 (bank spreading)
 constexpr int kCellW = 17;    // the same in dwords
 constexpr int kPreMax = 16;   // grid dwords per lane fetched per batch when a grid is not prefetched
@@ -117,6 +120,13 @@ __device__ __forceinline__ uint32_t place_dyn(const Params& p, const uint8_t* g,
   return (uint32_t)x | ((uint32_t)y << 6) | ((uint32_t)dir << 12) | (err << 16);
 }
 
+// clamp(v, -1, hi) in one instruction (hipcc only forms v_med3_i32 when it can prove lo <= hi)
+__device__ __forceinline__ int clamp_ring(int v, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(v), "v"(hi));
+  return r;
+}
+
 // gen_obs_grid (multigrid.py:997-1035) from this env's own grid: view cell (vx,vy) = world cell
 // pos + f*(V-1-vy) + r*(vx-V/2); cells outside the grid are Grid.slice's grey walls (:315), reached
 // by clamping each coordinate onto the ring; the own cell shows the carried object (:1029-1033).
@@ -126,31 +136,43 @@ template <int V>
 __device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, const uint32_t* lut, uint32_t me, uint32_t ck,
                                          uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t& vm) {
   const int x = aw_x(me), y = aw_y(me), d = aw_d(me);
-  const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
-  const int rx = -fy, ry = fx;
-  const int x0 = x + fx * (V - 1) - rx * (V / 2), y0 = y + fy * (V - 1) - ry * (V / 2);   // view cell (0,0)
+  // vx runs along the agent's right axis and vy against its forward axis; one of the two is world x, the other world
+  // y, so each needs one clamped coordinate per step, scaled by that axis' byte stride (x: a cell, y: a padded row)
+  const bool fwd_x = (d & 1) == 0;                       // facing east or west
+  const int fs = (d == 0 || d == 1) ? 1 : -1;            // DIR_TO_VEC: east (1,0), south (0,1), west (-1,0), north (0,-1)
+  const int rs = (d == 1 || d == 2) ? -1 : 1;            // right = (-f.y, f.x): east (0,1), south (-1,0), west (0,-1), north (1,0)
   const int PWB = __mul24(p.W + 2, kCellB);
-  const int cx0 = min(max(x0, -1), p.W), cy0 = min(max(y0, -1), p.H);
+  const int Sr = fwd_x ? PWB : kCellB, Sf = fwd_x ? kCellB : PWB;
+  const int Lr = fwd_x ? p.H : p.W, Lf = fwd_x ? p.W : p.H;
+  int r = (fwd_x ? y : x) - rs * (V / 2), f = (fwd_x ? x : y) + fs * (V - 1);   // view cell (0, 0)
   int U[V], Vv[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) {
-    const int ux = min(max(x0 + i * rx, -1), p.W) - cx0, uy = min(max(y0 + i * ry, -1), p.H) - cy0;
-    const int wx = min(max(x0 - i * fx, -1), p.W) + 1, wy = min(max(y0 - i * fy, -1), p.H) + 1;
-    U[i] = __mul24(uy, PWB) + __mul24(ux, kCellB);
-    Vv[i] = __mul24(wy, PWB) + __mul24(wx, kCellB);
+    U[i] = __mul24(clamp_ring(r, Lr), Sr) + Sr;          // (coordinate + 1) * stride: the ring is row / column 0
+    Vv[i] = __mul24(clamp_ring(f, Lf), Sf) + Sf;
+    r += rs;
+    f -= fs;
   }
   uint32_t code[V * V];
   uint32_t opq[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) opq[j] = 0;
+  // three passes, each over all cells, so that the two dependent LDS reads of a cell (kind byte, then its LUT word)
+  // are in flight for many cells at once instead of a handful (two waves per SIMD do not hide the round trips)
+#pragma unroll
+  for (int c = 0; c < V * V; ++c) code[c] = g_get(g, U[c / V] + Vv[c % V]);
+#if MG_VIEW_PHASES
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+  for (int c = 0; c < V * V; ++c) code[c] = lut[code[c]];
+#if MG_VIEW_PHASES
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
   for (int vx = V - 1; vx >= 0; --vx)
 #pragma unroll
-    for (int vy = 0; vy < V; ++vy) {
-      const uint32_t w = lut[g_get(g, U[vx] + Vv[vy])];
-      code[vx * V + vy] = w;
-      opq[vy] = view_row_bit(opq[vy], w);
-    }
+    for (int vy = 0; vy < V; ++vy) opq[vy] = view_row_bit(opq[vy], code[vx * V + vy]);
   pack_view<V>(code, opq, p.see_through != 0, lut[ck] & 0xFFFFFFu, s, vm);
 }
 
