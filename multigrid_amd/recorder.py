@@ -21,7 +21,7 @@ generate_trajectory_video.py:180-241).  Purpose: make bit-exact parity reproduci
 
 Fixture schema (E episodes, T = longest episode, A agents, V view size):
   meta          json: schema, kind ('static' | 'doorkey' | 'cluttered' | 'meetup'), width, height, n_agents, view_size,
-                max_steps, see_through_walls, competitive, shaping ('none' | 'v8'), source
+                max_steps, see_through_walls, competitive, shaping ('none' | 'v8' | 'v7'), source
   cells         uint8[H, W, 3]            layout (kind 'static'), encode() triples
   length        int32[E]                  steps recorded for the episode (it ended with done, or at T)
   spawn         int8[E, A, 4]             (x, y, dir, 0) accepted at reset
@@ -221,7 +221,8 @@ def replay_on_device(rec, device=0, check_state=True):
   shaped = 'shaped_reward' in rec
   kw = dict(n_envs=E, n_agents=A, view_size=m['view_size'], max_steps=m['max_steps'],
             see_through_walls=bool(m.get('see_through_walls', False)), competitive=bool(m.get('competitive', False)),
-            shaping='v8' if shaped else None, auto_reset=False, device=device, emit_env_reward=True)
+            shaping=(m.get('shaping') if m.get('shaping') in ('v7', 'v8') else 'v8') if shaped else None, auto_reset=False,
+            device=device, emit_env_reward=True)
   full = m['kind'] == 'meetup'
   if m['kind'] == 'doorkey':
     env = BatchedMultiGrid(None, kind='doorkey', size=m['width'], **kw)
@@ -307,6 +308,20 @@ class _V8Shaper:
     return self.ctl.shape_rewards(self.ns, [env.agent_pos[i] for i in range(env.n_agents)], rewards, actions)
 
 
+class _V7Shaper:
+  """The reference's own StableRewardShaper (v7_stable_goal_focused_ppo.py:35-108); `clear` is its `reset`, which the
+  v7 loop calls wherever it resets the env (v7:291,338)."""
+
+  def __init__(self, v7_module, env):
+    self.sh = v7_module.StableRewardShaper(env.n_agents)
+
+  def clear(self):
+    self.sh.reset()
+
+  def __call__(self, env, rewards, actions):
+    return self.sh.shape_rewards(env, [env.agent_pos[i] for i in range(env.n_agents)], rewards, actions)
+
+
 def record_reference(reference_path, env_id, episodes, seed=0, shaping='v8', max_len=None):
   import importlib
   import sys
@@ -319,7 +334,11 @@ def record_reference(reference_path, env_id, episodes, seed=0, shaping='v8', max
   env = gym.make(env_id)
   base = env.unwrapped
   kind = 'doorkey' if 'DoorKey' in env_id else 'static'
-  shaper = _V8Shaper(importlib.import_module('v8_robust_ppo'), base) if shaping == 'v8' else None
+  shaper = None
+  if shaping == 'v8':
+    shaper = _V8Shaper(importlib.import_module('v8_robust_ppo'), base)
+  elif shaping == 'v7':
+    shaper = _V7Shaper(importlib.import_module('v7_stable_goal_focused_ppo'), base)
   rec = Recorder(base, shaper=shaper, kind=kind)
   rng = np.random.RandomState(seed)
   policy = lambda e, obs, t: rng.randint(0, 7, size=e.n_agents)
@@ -347,7 +366,7 @@ def main(argv=None):
   r.add_argument('--env-id', default='MultiGrid-Cluttered-Fixed-15x15')
   r.add_argument('--episodes', type=int, default=16)
   r.add_argument('--seed', type=int, default=0)
-  r.add_argument('--shaping', default='v8', choices=['v8', 'none'])
+  r.add_argument('--shaping', default='v8', choices=['v8', 'v7', 'none'])
   r.add_argument('--out', required=True)
   p = sub.add_parser('replay', help='replay a fixture on the GPU and compare bit for bit')
   p.add_argument('fixture')

@@ -25,7 +25,8 @@ def replay_on_oracle(rec):
   bad = 0
   for e in range(E):
     env = c_oracle.OracleEnv(rec.get('cells') if m['kind'] == 'static' else None, W=m['width'], H=m['height'], A=A,
-                             V=m['view_size'], max_steps=m['max_steps'], shaping=int(shaped), kind=m['kind'],
+                             V=m['view_size'], max_steps=m['max_steps'], shaping=(2 if m.get('shaping') == 'v7' else 1) if shaped else 0,
+                             kind=m['kind'],
                              n_goals=m.get('n_goals', 0), n_clutter=m.get('n_clutter', 0), lava=m.get('walls_are_lava', False))
     if m['kind'] in ('cluttered', 'meetup'):
       obs = env.reset(spawn=rec['spawn'][e, :, :3], scatter=rec['scatter'][e])
@@ -86,6 +87,46 @@ def test_record_save_load_round_trip(tmp_path, cluttered_cells):
   assert replay_on_oracle(back) == 0
 
 
+class _PyV7:
+  """py_ref_env.V7Shaper behind the recorder's shaper protocol"""
+
+  def __init__(self, env):
+    self.sh = py_ref_env.V7Shaper(env)
+    self.clear = self.sh.clear
+
+  def __call__(self, env, rewards, actions):
+    return self.sh.shape([env.agent_pos[i] for i in range(env.n_agents)], rewards, list(actions))
+
+
+def _record_v7(cells, tmp_path, episodes=4, T=60):
+  A = 3
+
+  def order_fn():
+    o = np.arange(A)
+    np.random.shuffle(o)
+    return o
+
+  np.random.seed(12)
+  env = py_ref_env.PyRefEnv(cells, n_agents=A, view_size=5, max_steps=T, seed=21, order_fn=order_fn)
+  rng = np.random.RandomState(2)
+  r = recorder.Recorder(env, shaper=_PyV7(env))
+  eps = [r.episode(lambda e, obs, t: rng.choice(7, size=A, p=[.1, .1, .45, .05, .05, .05, .2]), T) for _ in range(episodes)]
+  meta = dict(kind='static', width=15, height=15, n_agents=A, view_size=5, max_steps=T, see_through_walls=False,
+              competitive=False, shaping='v7', source='test')
+  path = str(tmp_path / 'v7.npz')
+  recorder.save(path, recorder.stack_episodes(eps, meta, cells))
+  return recorder.load(path)
+
+
+def test_v7_shaped_recording_replays_on_the_c_oracle(empty_cells, tmp_path):
+  """meta.shaping = 'v7' selects the v7 shaper on replay (StableRewardShaper, v7_stable_goal_focused_ppo.py:60-108)"""
+  rec = _record_v7(empty_cells, tmp_path)
+  assert 'shaped_reward' in rec and (rec['shaped_reward'] == -0.05).any()      # idling agents reached the capped penalty
+  assert replay_on_oracle(rec) == 0
+  rec['meta']['shaping'] = 'v8'                                                # the wrong shaper must not replay clean
+  assert replay_on_oracle(rec) > 0
+
+
 def test_pre_schema_fixture_gets_meta():
   rec = recorder.load(os.path.join(GOLDEN, 'replay_cluttered_fixed_15x15.npz'))
   assert rec['meta']['schema'] == 0 and rec['meta']['n_agents'] == 3 and rec['meta']['shaping'] == 'v8'
@@ -109,3 +150,13 @@ def test_fixture_replays_on_the_gpu(name):
   rep = recorder.replay_on_device(rec)
   assert rep['mismatches'] == {}, rep
   assert rep['steps'] == int(rec['length'].sum())
+
+
+@pytest.mark.gpu
+def test_v7_shaped_recording_replays_on_the_gpu(empty_cells, tmp_path):
+  torch = pytest.importorskip('torch')
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  rec = _record_v7(empty_cells, tmp_path)
+  rep = recorder.replay_on_device(rec)
+  assert rep['mismatches'] == {}, rep
