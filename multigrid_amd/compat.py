@@ -76,8 +76,12 @@ class RefCompatEnv:
   """One env (N = 1) with the reference's list-of-arrays contract; rewards are the unshaped env
   rewards unless the batched env was built with shaping='v8'."""
 
-  def __init__(self, batched):
+  def __init__(self, batched, minigrid_mode=False):
     assert batched.n_envs == 1
+    # minigrid_mode (multigrid.py:400-416, 983-984, 1053-1054): one agent only; Discrete actions, the image (not a
+    # list of images) in the observation, a scalar reward
+    assert not minigrid_mode or batched.n_agents == 1, 'Backwards compatibility with minigrid only possible with 1 agent'
+    self.minigrid_mode = bool(minigrid_mode)
     self.b = batched
     self.n_agents = batched.n_agents
     self.width, self.height = batched.width, batched.height
@@ -91,8 +95,17 @@ class RefCompatEnv:
                               'direction': Box(0, 3, (A,), 'uint8')}
     if batched.obs_full is not None:
       self.observation_space['position'] = Box(0, max(batched.width, batched.height), (A, 2), 'uint8')
+    if self.minigrid_mode:
+      self.action_space = Discrete(7)                                              # multigrid.py:410-412
+      self.observation_space['image'] = Box(0, 255, img_shape[1:], 'uint8')        # multigrid.py:413-418
 
   def _obs(self):
+    obs = self._obs_lists()
+    if self.minigrid_mode:
+      obs['image'] = obs['image'][0]             # multigrid.py:1053-1054 (direction stays a list)
+    return obs
+
+  def _obs_lists(self):
     d = self.b.obs_dir[:, 0].cpu().numpy()
     if self.b.obs_full is not None:            # fully_observed (multigrid.py:1043-1065)
       full = self.b.obs_full[0].cpu().numpy()
@@ -112,7 +125,8 @@ class RefCompatEnv:
     self.b.step(a)
     rew = self.b.reward[:, 0].cpu().numpy()
     done = bool(self.b.done[0].item())
-    return self._obs(), [float(r) if r != 0 else 0 for r in rew], done, {}
+    rewards = [float(r) if r != 0 else 0 for r in rew]
+    return self._obs(), rewards[0] if self.minigrid_mode else rewards, done, {}   # multigrid.py:983-984
 
   @property
   def agent_pos(self):

@@ -30,6 +30,14 @@ register('MultiGrid-Cluttered-Fixed-15x15', dict(
     layout=layouts.cluttered_fixed_15x15, n_agents=3, view_size=5, max_steps=100,
     see_through_walls=False, competitive=False))
 
+# ClutteredMultiGridSingleFixed / ...6x6 (cluttered.py:201-211, 311-320): the same seed-52 procedure with one agent
+# (the 15x15 layout is the benchmark's: walls and goal are placed before the agents), and on a 6x6 grid with 5 walls.
+register('MultiGrid-Cluttered-Fixed-Single-v0', dict(
+    layout=layouts.cluttered_fixed_15x15, n_agents=1, view_size=5, max_steps=100, see_through_walls=False, competitive=False))
+register('MultiGrid-Cluttered-Fixed-Single-6x6-v0', dict(
+    layout=(lambda: layouts.cluttered(size=6, n_clutter=5, randomize_goal=False, seed=52)), n_agents=1, view_size=5,
+    max_steps=100, see_through_walls=False, competitive=False))
+
 # EmptyEnv with agent_start='random' (multigrid_envs/empty.py:28-60, 106-117): border walls, goal at (size-2, size-2),
 # agents anywhere, view 5, see_through_walls=True, max_steps 2*size^2 — a static layout.
 for _id, _size, _agents in (('MultiGrid-Empty-Random-5x5-v0', 5, 2), ('MultiGrid-Empty-Random-8x8-v0', 8, 3)):
@@ -53,15 +61,33 @@ for _id, _size, _agents in (('MultiGrid-DoorKey-6x6-v0', 6, 2), ('MultiGrid-Door
                      see_through_walls=False, competitive=False))
 
 # ClutteredMultiGrid with a fresh layout per reset (multigrid_envs/cluttered.py:13-45, 187-199, 290-324).
-# The *-Minigrid-* ids differ only in minigrid_mode (container shapes, multigrid.py:983,1053) and are not listed.
 for _id, _size, _agents, _clutter, _steps in (('MultiGrid-Cluttered-v0', 15, 3, 25, 250),
                                              ('MultiGrid-Cluttered-Single-v0', 15, 1, 25, 250),
                                              ('MultiGrid-Cluttered-Single-6x6-v0', 6, 1, 5, 50)):
   register(_id, dict(kind='cluttered', size=_size, n_agents=_agents, view_size=5, max_steps=_steps, n_goals=1,
                      n_clutter=_clutter, see_through_walls=False, competitive=False))
 
+# The single-agent *-Minigrid-* ids (cluttered.py:213-285, 326-381; empty.py:148-163, 203-212; fourrooms.py:136-157, 181-195):
+# minigrid_mode only changes container shapes on the host side (compat.RefCompatEnv); the device env is the same kind.
+# EmptyEnv with randomize_goal draws wall_rect, goal, agents (empty.py:55-69) — ClutteredMultiGrid's sequence with no clutter.
+for _id, _size, _clutter, _lava in (('MultiGrid-Cluttered40-Minigrid-v0', 15, 40, False), ('MultiGrid-Cluttered10-Minigrid-v0', 15, 10, False),
+                                    ('MultiGrid-Cluttered50-Minigrid-v0', 15, 50, False), ('MultiGrid-Cluttered5-Minigrid-v0', 15, 5, False),
+                                    ('MultiGrid-MiniCluttered1-Minigrid-v0', 6, 1, False), ('MultiGrid-MiniCluttered6-Minigrid-v0', 6, 6, False),
+                                    ('MultiGrid-MiniCluttered7-Minigrid-v0', 6, 7, False),
+                                    ('MultiGrid-Cluttered-Lava-Minigrid-v0', 15, 25, True), ('MultiGrid-MiniCluttered-Lava-Minigrid-v0', 6, 4, True),
+                                    ('MultiGrid-MediumCluttered-Lava-Minigrid-v0', 10, 15, True),
+                                    ('MultiGrid-MediumCluttered15-Minigrid-v0', 10, 15, False)):
+  register(_id, dict(kind='cluttered', size=_size, n_agents=1, view_size=5, max_steps=250, n_goals=1, n_clutter=_clutter,
+                     walls_are_lava=_lava, see_through_walls=False, competitive=False, minigrid_mode=True))
+for _id, _size in (('MultiGrid-Empty-Random-6x6-Minigrid-v0', 6), ('MultiGrid-Empty-Random-15x15-Minigrid-v0', 15)):
+  register(_id, dict(kind='cluttered', size=_size, n_agents=1, view_size=5, max_steps=2 * _size * _size, n_goals=1, n_clutter=0,
+                     see_through_walls=True, competitive=False, minigrid_mode=True))
+for _id, _size in (('MultiGrid-FourRooms-Minigrid-v0', 15), ('MultiGrid-MiniFourRooms-Minigrid-v0', 6)):
+  register(_id, dict(kind='fourrooms', size=_size, n_agents=1, view_size=5, max_steps=100, see_through_walls=False,
+                     competitive=False, minigrid_mode=True))
+
 # FourRoomsEnv (multigrid_envs/fourrooms.py:25-134): max_steps 100, gaps / agents / goal drawn per reset.  The default
-# 19x19 id has five agents (not instantiated); the *-Minigrid-* and TwoRooms ids are not listed.
+# 19x19 id has five agents (not instantiated); the TwoRooms ids are not listed.
 register('MultiGrid-FourRooms-15x15-v0', dict(kind='fourrooms', size=15, n_agents=3, view_size=5, max_steps=100,
                                               see_through_walls=False, competitive=False))
 register('MultiGrid-FourRooms-Single-v0', dict(kind='fourrooms', size=19, n_agents=1, view_size=7, max_steps=100,
@@ -85,6 +111,7 @@ def make_batched(env_id, n_envs, **kw):
   from .batched import BatchedMultiGrid
   s = spec(env_id)
   cells = s.pop('layout')() if 'layout' in s else None
+  s.pop('minigrid_mode', None)          # host-side container shapes only (make)
   s.update(kw)
   return BatchedMultiGrid(cells, n_envs=n_envs, **s)
 
@@ -92,4 +119,4 @@ def make_batched(env_id, n_envs, **kw):
 def make(env_id, **kw):
   """gym.make(env_id) counterpart: one env with the reference's list-of-arrays contract."""
   from .compat import RefCompatEnv
-  return RefCompatEnv(make_batched(env_id, 1, **kw))
+  return RefCompatEnv(make_batched(env_id, 1, **kw), minigrid_mode=spec(env_id).get('minigrid_mode', False))

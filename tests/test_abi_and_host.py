@@ -76,6 +76,26 @@ def test_registry_mirrors_reference_ids():
     registry.register('Other-Env', {})
 
 
+def test_registry_specs_are_complete():
+  ids = registry.registered_ids()
+  assert len(ids) == 44
+  for i in ids:
+    s = registry.spec(i)
+    assert {'n_agents', 'view_size', 'max_steps', 'see_through_walls', 'competitive'} <= set(s), i
+    assert ('layout' in s) != ('kind' in s), i                      # a fixed layout or a generated kind
+    assert 1 <= s['n_agents'] <= 4, i
+    if s.get('minigrid_mode'):                                      # multigrid.py:406-408
+      assert s['n_agents'] == 1 and 'Minigrid' in i, i
+    if 'layout' in s:
+      cells = s['layout']()
+      assert cells.shape[2] == 3 and (cells[..., 0] == 8).sum() == 1, i
+  # cluttered.py:201-211: the single-agent fixed ids reuse the seed-52 procedure
+  a, b = registry.spec('MultiGrid-Cluttered-Fixed-Single-v0'), registry.spec('MultiGrid-Cluttered-Fixed-15x15')
+  assert (a['layout']() == b['layout']()).all() and a['n_agents'] == 1
+  six = registry.spec('MultiGrid-Cluttered-Fixed-Single-6x6-v0')['layout']()
+  assert six.shape == (6, 6, 3) and (six[1:-1, 1:-1, 0] == 2).sum() == 5 and tuple(six[4, 4]) == (8, 1, 0)
+
+
 def test_layout_generators():
   g = layouts.cluttered(size=15, n_clutter=25, randomize_goal=True, seed=7)
   assert int((g[:, :, 0] == 8).sum()) == 1 and int((g[1:-1, 1:-1, 0] == 2).sum()) == 25
