@@ -76,11 +76,13 @@ extern "C" {
 #define MG_KIND_DOORKEY   1
 #define MG_KIND_CLUTTERED 2
 #define MG_KIND_MEETUP    3
-#define MG_KIND_FOURROOMS 4   /* FourRoomsEnv._gen_grid with two_rooms=False, random agents and goal (multigrid_envs/
+#define MG_KIND_FOURROOMS 4   /* FourRoomsEnv._gen_grid (two_rooms with MG_GEN_TWO_ROOMS), random agents and goal (multigrid_envs/
                                  fourrooms.py:53-104): walls at x = W/2 and y = H/2 with one random gap per segment, drawn per
                                  env and per reset; the goal is placed after the agents.  Injected as three scatter pairs:
                                  (gap_top_y, gap_left_x), (gap_right_x, gap_bottom_y), (goal_x, goal_y). */
 #define MG_GEN_LAVA 1      /* gen_flags: Cluttered walls_are_lava */
+#define MG_GEN_TWO_ROOMS 2 /* gen_flags: FourRooms two_rooms=True (fourrooms.py:75-83): only the vertical wall is built; its lower
+                              gap is not drawn on grids with height < 7 */
 #define MG_MAX_SCATTER 64  /* gen_n_goals + gen_n_clutter */
 
 /* One-byte cell kind of the mutable per-env grids (mg_buffers.grid, carried objects):

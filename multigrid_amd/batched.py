@@ -33,7 +33,7 @@ class BatchedMultiGrid:
   def __init__(self, cells, n_envs, n_agents=3, view_size=5, max_steps=100, see_through_walls=False,
                competitive=False, shaping='v8', auto_reset=True, device=0, seed=0,
                env_id_base=0, emit_env_reward=False, use_torch_stream=True, kernel_path='auto',
-               kind='static', size=None, n_goals=0, n_clutter=0, walls_are_lava=False, fixed_spawn=None,
+               kind='static', size=None, n_goals=0, n_clutter=0, walls_are_lava=False, two_rooms=False, fixed_spawn=None,
                fixed_mode='always'):
     """kind='static': `cells` uint8[H, W, 3] is the layout every reset starts from (objects allowed).
     kind='doorkey' | 'cluttered' | 'meetup': `cells` is None and `size` the grid size; layouts are drawn
@@ -59,7 +59,7 @@ class BatchedMultiGrid:
         see_through_walls=int(see_through_walls), competitive=int(competitive),
         shaping_kind={None: 0, 'none': 0, 'v8': 1, 'v7': 2}[shaping], auto_reset=int(auto_reset),
         env_kind=_lib.KINDS[kind], emit_env_reward=int(emit_env_reward),
-        gen_n_goals=int(n_goals), gen_n_clutter=int(n_clutter), gen_flags=_lib.GEN_LAVA if walls_are_lava else 0,
+        gen_n_goals=int(n_goals), gen_n_clutter=int(n_clutter), gen_flags=(_lib.GEN_LAVA if walls_are_lava else 0) | (_lib.GEN_TWO_ROOMS if two_rooms else 0),
         kernel_path={'auto': 0, 'generic': 1, 'table': 2}[kernel_path],
         n_envs=n_envs, env_id_base=env_id_base, seed=seed)
     self.h = C.c_void_p()

@@ -554,15 +554,20 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
         g2 = rw + 1 + (int)__umulhi(r.z, (uint32_t)(rw - 1));
         g3 = rh + 1 + (int)__umulhi(r.w, (uint32_t)(rh - 1));
       }
+      // two_rooms (fourrooms.py:75-83): no horizontal wall and no draw for it; the lower gap is neither drawn nor
+      // carved when height < 7
+      const bool two = (p.gen_flags & MG_GEN_TWO_ROOMS) != 0, low = !(two && p.H < 7);
+      if (two) { g1 = 1; g2 = rw + 1; }
+      if (!low) g3 = rh + 1;
       if (g0 < 1 || g0 >= rh || g1 < 1 || g1 >= rw || g2 <= rw || g2 >= 2 * rw || g3 <= rh || g3 >= 2 * rh) {
         err |= MG_ERR_BAD_RESPAWN; g0 = 1; g1 = 1; g2 = rw + 1; g3 = rh + 1;
       }
       for (int y = 0; y < 2 * rh; ++y) gs(g_off(p, rw, y), K_WALL);
-      for (int x = 0; x < 2 * rw; ++x) gs(g_off(p, x, rh), K_WALL);
+      if (!two) for (int x = 0; x < 2 * rw; ++x) gs(g_off(p, x, rh), K_WALL);
       if (g0 < p.H - 1) gs(g_off(p, rw, g0), 0u);                               // x = rw is never <= 1 for W >= 6
-      if (g1 > 1) gs(g_off(p, g1, rh), 0u);
-      if (g2 < p.W - 1) gs(g_off(p, g2, rh), 0u);
-      if (g3 < p.H - 1) gs(g_off(p, rw, g3), 0u);
+      if (!two && g1 > 1) gs(g_off(p, g1, rh), 0u);
+      if (!two && g2 < p.W - 1) gs(g_off(p, g2, rh), 0u);
+      if (low && g3 < p.H - 1) gs(g_off(p, rw, g3), 0u);
     }
 #pragma unroll 1
     for (int a = 0; a < A; ++a) {                                               // place_agent, in agent order

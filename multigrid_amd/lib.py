@@ -13,6 +13,7 @@ KIND_STATIC, KIND_DOORKEY, KIND_CLUTTERED, KIND_MEETUP, KIND_FOURROOMS = 0, 1, 2
 KINDS = {'static': KIND_STATIC, 'doorkey': KIND_DOORKEY, 'cluttered': KIND_CLUTTERED, 'meetup': KIND_MEETUP,
          'fourrooms': KIND_FOURROOMS}
 GEN_LAVA = 1
+GEN_TWO_ROOMS = 2
 FIXED_OFF, FIXED_ALWAYS, FIXED_AT_RESET = 0, 1, 2
 
 

@@ -82,12 +82,13 @@ for _id, _size, _clutter, _lava in (('MultiGrid-Cluttered40-Minigrid-v0', 15, 40
 for _id, _size in (('MultiGrid-Empty-Random-6x6-Minigrid-v0', 6), ('MultiGrid-Empty-Random-15x15-Minigrid-v0', 15)):
   register(_id, dict(kind='cluttered', size=_size, n_agents=1, view_size=5, max_steps=2 * _size * _size, n_goals=1, n_clutter=0,
                      see_through_walls=True, competitive=False, minigrid_mode=True))
-for _id, _size in (('MultiGrid-FourRooms-Minigrid-v0', 15), ('MultiGrid-MiniFourRooms-Minigrid-v0', 6)):
+for _id, _size, _two in (('MultiGrid-FourRooms-Minigrid-v0', 15, False), ('MultiGrid-MiniFourRooms-Minigrid-v0', 6, False),
+                         ('MultiGrid-TwoRooms-Minigrid-v0', 15, True), ('MultiGrid-MiniTwoRooms-Minigrid-v0', 6, True)):
   register(_id, dict(kind='fourrooms', size=_size, n_agents=1, view_size=5, max_steps=100, see_through_walls=False,
-                     competitive=False, minigrid_mode=True))
+                     competitive=False, two_rooms=_two, minigrid_mode=True))
 
 # FourRoomsEnv (multigrid_envs/fourrooms.py:25-134): max_steps 100, gaps / agents / goal drawn per reset.  The default
-# 19x19 id has five agents (not instantiated); the TwoRooms ids are not listed.
+# 19x19 id has five agents (not instantiated).
 register('MultiGrid-FourRooms-15x15-v0', dict(kind='fourrooms', size=15, n_agents=3, view_size=5, max_steps=100,
                                               see_through_walls=False, competitive=False))
 register('MultiGrid-FourRooms-Single-v0', dict(kind='fourrooms', size=19, n_agents=1, view_size=7, max_steps=100,

@@ -65,6 +65,7 @@ def lib():
     L.mgo_batch_step.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, u8p, i8p, i8p,
                                  C.c_uint64, u8p, u8p, f64p, f64p, u8p, u8p]
     L.mgo_set_kind.argtypes = [C.c_void_p, C.c_int]
+    L.mgo_set_two_rooms.argtypes = [C.c_void_p, C.c_int]
     L.mgo_reset_gen.argtypes = [C.c_void_p, i8p, i8p, C.c_uint64]
     L.mgo_step_ex.argtypes = [C.c_void_p, i32p, u8p, i8p, i8p, i8p, i8p, C.c_uint64, u8p, u8p, f64p, f64p, u8p]
     L.mgo_carry_word.restype = C.c_uint32
@@ -100,11 +101,13 @@ MAXOBJ = 64
 FIXED_ALWAYS, FIXED_AT_RESET = 1, 2     # mgo_set_fixed_spawn modes (EmptyEnv fixed start / MazeEnv)
 
 
-def _configure(L, h, kind, n_goals, n_clutter, lava, fixed_spawn=None, fixed_mode=0):
+def _configure(L, h, kind, n_goals, n_clutter, lava, fixed_spawn=None, fixed_mode=0, two_rooms=False):
   if fixed_spawn is not None:
     xy = np.ascontiguousarray(fixed_spawn, np.int8)
     L.mgo_set_fixed_spawn(h, _p(xy, i8p), fixed_mode)
   L.mgo_set_kind(h, KINDS[kind])
+  if two_rooms:
+    L.mgo_set_two_rooms(h, 1)
   if kind in ('cluttered', 'meetup'):
     if not L.mgo_set_scatter(h, n_goals, n_clutter, int(lava)):
       raise ValueError('bad scatter generator parameters')
@@ -156,13 +159,13 @@ class OracleEnv:
 
   def __init__(self, cells, W=15, H=15, A=3, V=5, max_steps=100, see_through=0, competitive=0,
                shaping=0, auto_reset=0, seed=0, gid=0, kind='static', n_goals=0, n_clutter=0, lava=False,
-               fixed_spawn=None, fixed_mode=0):
+               fixed_spawn=None, fixed_mode=0, two_rooms=False):
     self.L = lib()
     self.W, self.H, self.A, self.V = W, H, A, V
     self.h = self.L.mgo_create(W, H, A, V, max_steps, see_through, competitive, shaping, auto_reset, seed, gid)
     if not self.h:
       raise ValueError('bad oracle config')
-    _configure(self.L, self.h, kind, n_goals, n_clutter, lava, fixed_spawn, fixed_mode)
+    _configure(self.L, self.h, kind, n_goals, n_clutter, lava, fixed_spawn, fixed_mode, two_rooms)
     self.n_obj = (n_goals + n_clutter) if kind in ('cluttered', 'meetup') else (3 if kind == 'fourrooms' else 0)
     self.full = kind == 'meetup'
     self.img_shape = (W, H, 3) if self.full else (V, V, 3)
@@ -292,7 +295,7 @@ class OracleBatch:
 
   def __init__(self, cells, n, W=15, H=15, A=3, V=5, max_steps=100, see_through=0, competitive=0,
                shaping=0, auto_reset=0, seed=0, gid_base=0, kind='static', n_goals=0, n_clutter=0, lava=False,
-               fixed_spawn=None, fixed_mode=0):
+               fixed_spawn=None, fixed_mode=0, two_rooms=False):
     self.L = lib()
     self.n, self.A, self.V, self.W, self.H = n, A, V, W, H
     self.n_obj = (n_goals + n_clutter) if kind in ('cluttered', 'meetup') else (3 if kind == 'fourrooms' else 0)
@@ -304,7 +307,7 @@ class OracleBatch:
       h = self.L.mgo_create(W, H, A, V, max_steps, see_through, competitive, shaping, auto_reset, seed, gid_base + i)
       if not h:
         raise ValueError('bad oracle config')
-      _configure(self.L, h, kind, n_goals, n_clutter, lava, fixed_spawn, fixed_mode)
+      _configure(self.L, h, kind, n_goals, n_clutter, lava, fixed_spawn, fixed_mode, two_rooms)
       if cells is not None:
         self.L.mgo_set_map(h, _p(cells, u8p))
       self.envs[i] = h

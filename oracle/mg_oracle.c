@@ -120,6 +120,7 @@ typedef struct mgo_env {
   /* scatter generators (ClutteredMultiGrid with random layouts, MeetupEnv): */
   int n_goals;                 /* Cluttered: 1 = randomize_goal, 0 = goal at (W-2,H-2); Meetup: number of goal doors */
   int n_clutter, lava;         /* obstacles per layout; Cluttered walls_are_lava */
+  int two_rooms;               /* FourRoomsEnv(two_rooms=True), fourrooms.py:32,75-85 */
   int full_obs;                /* fully_observed (multigrid.py:1043-1045, 1064-1065): Meetup */
   int goal_x[MAXGOALS], goal_y[MAXGOALS];   /* MeetupEnv.goal_pos (meetup.py:67-70) */
   int past_dist[MAXA];         /* MeetupEnv.past_goal_dist (meetup.py:61, 94) */
@@ -150,6 +151,7 @@ int mgo_set_scatter(mgo_env* e, int n_goals, int n_clutter, int lava) {
   e->n_goals = n_goals; e->n_clutter = n_clutter; e->lava = lava;
   return 1;
 }
+void mgo_set_two_rooms(mgo_env* e, int on) { e->two_rooms = on; }
 int mgo_obs_bytes(const mgo_env* e) { return e->full_obs ? e->W * e->H * 3 : e->V * e->V * 3; }
 void mgo_destroy(mgo_env* e) { free(e); }
 /* xy: [A][2] start cells; mode 0 switches the feature off */
@@ -507,6 +509,11 @@ static void gen_fourrooms(mgo_env* e) {
     g[2] = rw + 1 + (int)mulhi32(r[2], (uint32_t)(rw - 1));      /* i = 1 */
     g[3] = rh + 1 + (int)mulhi32(r[3], (uint32_t)(rh - 1));      /* j = 1 */
   }
+  /* two_rooms (fourrooms.py:75-83): only the vertical wall; `not (j == 1 and two_rooms and height < 7)` skips the lower
+   * gap's draw on small grids.  The unused entries take fixed in-range values so that the records stay comparable. */
+  const int two = e->two_rooms, low = !(two && H < 7);
+  if (two) { g[1] = 1; g[2] = rw + 1; }
+  if (!low) g[3] = rh + 1;
   if (g[0] < 1 || g[0] >= rh || g[1] < 1 || g[1] >= rw || g[2] <= rw || g[2] >= 2 * rw || g[3] <= rh || g[3] >= 2 * rh) {
     e->err |= ERR_BAD_RESPAWN; g[0] = 1; g[1] = 1; g[2] = rw + 1; g[3] = rh + 1;
   }
@@ -514,10 +521,12 @@ static void gen_fourrooms(mgo_env* e) {
   /* the loop of :68-90, in its order: (j=0,i=0) vertical top + gap, horizontal left + gap; (j=0,i=1) horizontal
    * right + gap; (j=1,i=0) vertical bottom + gap */
   for (int step = 0; step < 4; ++step) {
+    if (two && (step == 1 || step == 2)) continue;                                             /* `if not self.two_rooms` :85 */
     if (step == 0) for (int y = 0; y < rh; ++y) grid_set(&e->grid, rw, y, wall);            /* vert_wall(x_right, y_top, room_h) */
     if (step == 1) for (int x = 0; x < rw; ++x) grid_set(&e->grid, x, rh, wall);            /* horz_wall(x_left, y_bottom, room_w) */
     if (step == 2) for (int x = rw; x < 2 * rw; ++x) grid_set(&e->grid, x, rh, wall);
     if (step == 3) for (int y = rh; y < 2 * rh; ++y) grid_set(&e->grid, rw, y, wall);
+    if (step == 3 && !low) continue;                                                           /* :76 */
     if (!(gx[step] <= 1 || gx[step] >= W - 1 || gy[step] <= 0 || gy[step] >= H - 1)) grid_set(&e->grid, gx[step], gy[step], NONE);
   }
   e->last_scatter[0] = (int8_t)g[0]; e->last_scatter[1] = (int8_t)g[1];

@@ -628,9 +628,10 @@ class PyMeetupEnv(PyClutteredEnv):
 
 
 class PyFourRoomsEnv(PyClutteredEnv):
-  """FourRoomsEnv with two_rooms=False and no fixed agent / goal positions (multigrid_envs/fourrooms.py:25-107)."""
+  """FourRoomsEnv without fixed agent / goal positions (multigrid_envs/fourrooms.py:25-107)."""
 
-  def __init__(self, grid_size=19, n_agents=3, view_size=7, **kw):
+  def __init__(self, grid_size=19, n_agents=3, view_size=7, two_rooms=False, **kw):
+    self.two_rooms = two_rooms
     super().__init__(size=grid_size, n_agents=n_agents, n_clutter=0, view_size=view_size, max_steps=100, **kw)
 
   def _gen_grid(self):
@@ -649,8 +650,9 @@ class PyFourRoomsEnv(PyClutteredEnv):
         if i + 1 < 2:
           for y in range(y_top, y_top + room_h):
             self.grid.set(x_right, y, Wall())
-          carve((x_right, self.rand_int(y_top + 1, y_bottom)))
-        if j + 1 < 2:
+          if not (j == 1 and self.two_rooms and h < 7):                    # :76
+            carve((x_right, self.rand_int(y_top + 1, y_bottom)))
+        if not self.two_rooms and j + 1 < 2:                               # :83-85
           for x in range(x_left, x_left + room_w):
             self.grid.set(x, y_bottom, Wall())
           carve((self.rand_int(x_left + 1, x_right), y_bottom))

@@ -21,7 +21,7 @@ def _oracle_for(spec, cells, seed):
                               see_through=int(spec['see_through_walls']), competitive=int(spec['competitive']), shaping=1,
                               auto_reset=1, seed=seed, kind=spec.get('kind', 'static'), n_goals=spec.get('n_goals', 0),
                               n_clutter=spec.get('n_clutter', 0), lava=spec.get('walls_are_lava', False),
-                              fixed_spawn=spec.get('fixed_spawn'), fixed_mode=fixed)
+                              fixed_spawn=spec.get('fixed_spawn'), fixed_mode=fixed, two_rooms=spec.get('two_rooms', False))
 
 
 @pytest.mark.parametrize('env_id', registry.registered_ids())

@@ -127,22 +127,46 @@ def test_fourrooms_known_layout():
   assert env.aux_words()[0] == 13 | 13 << 6
 
 
-def _cross_fourrooms(size, A, V, steps, seed):
+def test_two_rooms_known_layouts():
+  """fourrooms.py:75-85 with two_rooms: only the wall at x = W/2; on a grid with height < 7 its lower gap is not drawn"""
+  env = c_oracle.OracleEnv(None, W=15, H=15, A=1, V=5, max_steps=100, kind='fourrooms', two_rooms=True)
+  env.reset(spawn=[(1, 1, 0)], scatter=[(3, 1), (10, 12), (13, 13)])      # the left / right entries are ignored
+  assert env.errors() == 0
+  g = env.grid()
+  wall, empty = (2, 5, 0), (1, 0, 0)
+  for k in range(1, 14):
+    assert tuple(g[k, 7]) == (empty if k in (3, 12) else wall), k
+    if k != 7:
+      assert tuple(g[7, k]) == empty, k
+  assert int((g[:, :, 0] == 2).sum()) == 56 + 13 - 2
+  env = c_oracle.OracleEnv(None, W=6, H=6, A=1, V=5, max_steps=100, kind='fourrooms', two_rooms=True)
+  env.reset(spawn=[(1, 1, 0)], scatter=[(2, 1), (4, 4), (4, 1)])          # top gap y = 2; the bottom entry is ignored
+  assert env.errors() == 0
+  g = env.grid()
+  assert [tuple(g[y, 3]) for y in range(1, 5)] == [wall, empty, wall, wall]
+  assert tuple(g[1, 4]) == (8, 1, 0)
+
+
+def _cross_fourrooms(size, A, V, steps, seed, two_rooms=False):
   rng = np.random.default_rng(seed)
-  c = c_oracle.OracleEnv(None, W=size, H=size, A=A, V=V, max_steps=100, kind='fourrooms', seed=seed, gid=seed + 5)
+  c = c_oracle.OracleEnv(None, W=size, H=size, A=A, V=V, max_steps=100, kind='fourrooms', seed=seed, gid=seed + 5,
+                         two_rooms=two_rooms)
   feed = Feed()
 
   def after_reset():
     sc = c.last_scatter()
     _, _, spawn = c.last_draws()
     q = [int(sc[0][0]), int(sc[0][1]), int(sc[1][0]), int(sc[1][1])]     # draw order: top, left, right, bottom
+    if two_rooms:                                                        # top, then bottom unless height < 7
+      q = [q[0]] + ([q[3]] if size >= 7 else [])
     for s_ in spawn:
       q += [int(s_[0]), int(s_[1]), int(s_[2])]
     return q + [int(sc[2][0]), int(sc[2][1])]
 
   c.reset()
   feed.q = after_reset()
-  py = py_ref_env.PyFourRoomsEnv(grid_size=size, n_agents=A, view_size=V, rand_int=feed.rand_int, order_fn=lambda: feed.order)
+  py = py_ref_env.PyFourRoomsEnv(grid_size=size, n_agents=A, view_size=V, two_rooms=two_rooms, rand_int=feed.rand_int,
+                                 order_fn=lambda: feed.order)
   assert not feed.q
   episodes = touches = 0
   for t in range(steps):
@@ -174,6 +198,13 @@ def test_fourrooms_cross():
   assert ep > 30 and touches > 0
   ep, _ = _cross_fourrooms(19, 1, 7, 400, seed=5)
   assert ep >= 3
+
+
+def test_two_rooms_cross():
+  ep, touches = _cross_fourrooms(15, 1, 5, 1200, seed=6, two_rooms=True)
+  assert ep >= 11
+  ep, touches = _cross_fourrooms(6, 1, 5, 2500, seed=7, two_rooms=True)
+  assert ep > 30 and touches > 0
 
 
 def test_meetup_cross_6x6():
