@@ -287,3 +287,24 @@ def test_graph_rollout_is_self_consistent():
   losses = ctl.update(traj, epochs=1)
   assert all(np.isfinite(l) for l in losses)
   env.close(); twin.close()
+
+
+@pytest.mark.gpu
+def test_untrained_returns_agree_with_the_reference_log():
+  """Statistical sanity only, not parity: the reference's own v8 run (models8/results_simple_...json, `collective_rewards`)
+  starts at -4.58, -8.11, -9.38, -9.23, -7.98 per episode (mean of its first ten: -6.3, s.d. 3.6) before learning takes
+  hold.  The whole path here (layout, spawn, step, v8 shaping, freshly initialised nets, 100-step episodes) must land
+  in the same place: 4096 untrained episodes average about -7.0."""
+  torch = pytest.importorskip('torch')
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  import multigrid_amd
+  from multigrid_amd import ppo
+  env = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', 4096, seed=5)
+  env.reset()
+  ctl = ppo.BatchedController(env, ddp=False, seed=6)
+  traj = ctl.rollout(100)
+  ret = torch.stack(traj['reward']).double().sum(dim=(0, 1))          # collective return per episode (v8:425)
+  mean, sd = float(ret.mean()), float(ret.std())
+  assert -9.5 < mean < -4.5, mean          # reference's first ten episodes: -6.3 +- 3.6 / sqrt(10)
+  assert 1.5 < sd < 8.0, sd                # its episode-to-episode spread there: 3.6
