@@ -82,6 +82,8 @@ class RefCompatEnv:
     # list of images) in the observation, a scalar reward
     assert not minigrid_mode or batched.n_agents == 1, 'Backwards compatibility with minigrid only possible with 1 agent'
     self.minigrid_mode = bool(minigrid_mode)
+    # MeetupEnv.step builds its own reward list after the base step (meetup.py:86-96): it stays a list even in minigrid_mode
+    self._scalar_reward = self.minigrid_mode and batched.obs_full is None
     self.b = batched
     self.n_agents = batched.n_agents
     self.width, self.height = batched.width, batched.height
@@ -126,7 +128,7 @@ class RefCompatEnv:
     rew = self.b.reward[:, 0].cpu().numpy()
     done = bool(self.b.done[0].item())
     rewards = [float(r) if r != 0 else 0 for r in rew]
-    return self._obs(), rewards[0] if self.minigrid_mode else rewards, done, {}   # multigrid.py:983-984
+    return self._obs(), rewards[0] if self._scalar_reward else rewards, done, {}   # multigrid.py:983-984
 
   @property
   def agent_pos(self):

@@ -71,3 +71,16 @@ def test_minigrid_mode_container_shapes(env_id):
   obs, reward, done, info = env.step([1])
   assert not isinstance(reward, list)
   env.close()
+
+
+def test_meetup_minigrid_keeps_its_reward_list():
+  """meetup.py:86-96 rebuilds the reward list after the base step, so minigrid_mode only unwraps the image"""
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  import multigrid_amd
+  env = multigrid_amd.make('MultiGrid-Meetup-Random-8x8-Minigrid-v0', shaping=None, auto_reset=False, seed=3)
+  obs = env.reset()
+  assert obs['image'].shape == (8, 8, 3) and len(obs['position']) == 1
+  obs, reward, done, _ = env.step(2)
+  assert isinstance(reward, list) and len(reward) == 1 and obs['image'].shape == (8, 8, 3)
+  env.close()
