@@ -68,7 +68,7 @@ extern "C" {
  *   CLUTTERED = ClutteredMultiGrid._gen_grid (multigrid_envs/cluttered.py:25-40) drawn on device per env and
  *             per reset: border walls, a goal (scattered when gen_n_goals = 1 = randomize_goal, at (W-2,H-2)
  *             when 0), gen_n_clutter walls (lava with MG_GEN_LAVA) scattered by place_obj, agents anywhere.
- *   MEETUP  = MeetupEnv (multigrid_envs/meetup.py:26-95): gen_n_goals (1..3) locked red doors as meeting
+ *   MEETUP  = MeetupEnv (multigrid_envs/meetup.py:26-95): gen_n_goals (1..6) locked red doors as meeting
  *             points and gen_n_clutter walls scattered, fully observed (obs = the whole encoded grid,
  *             mg_buffers.obs_full, multigrid.py:1043-1045), reward = decrease of the Manhattan distance to the
  *             jointly closest goal, +1 and done when every agent stands next to it (meetup.py:78-95). */
@@ -166,10 +166,11 @@ typedef struct mg_buffers {
                             LDS address is linear in the cell index; use mg_export_grid for a plain [n][H*W] copy. */
   int32_t  grid_words;   /* ceil(W*H/4) */
   int32_t  mutable_grid;
-  uint32_t* aux;         /* MEETUP, CLUTTERED, FOURROOMS, [env_stride][4]: words 0..2 = MeetupEnv.goal_pos[k] as x | y<<6
-                            (0xFFFFFFFF if unused), word 3 = past_goal_dist, one byte per agent (meetup.py:61,70,94);
-                            CLUTTERED with a scattered goal / FOURROOMS: word 0 = the env's goal cell (what the v8
-                            shaper's get_goal_position finds, v8_robust_ppo.py:159-169) */
+  uint32_t* aux;         /* MEETUP, CLUTTERED, FOURROOMS, [env_stride][4]: words 0..2 = MeetupEnv.goal_pos, two per word
+                            (goal 2k in bits 0..15 of word k, goal 2k+1 in bits 16..31, each x | y<<6, 0xFFFF if unused:
+                            up to six goals), word 3 = past_goal_dist, one byte per agent (meetup.py:61,70,94);
+                            CLUTTERED with a scattered goal / FOURROOMS: bits 0..15 of word 0 = the env's goal cell (what
+                            the v8 shaper's get_goal_position finds, v8_robust_ppo.py:159-169) */
   uint8_t* obs_full;     /* fully observed kinds (MEETUP) only, [env_stride][W*H*3]: Grid.encode() of the whole grid,
                             [x][y][(type,color,state)] with the agents in their cells as (10, id, dir); the same image
                             for every agent (multigrid.py:1043-1045), obs['position'][a] is in env_state.  obs_image is

@@ -38,7 +38,7 @@ class BatchedMultiGrid:
     """kind='static': `cells` uint8[H, W, 3] is the layout every reset starts from (objects allowed).
     kind='doorkey' | 'cluttered' | 'meetup': `cells` is None and `size` the grid size; layouts are drawn
     on device per env and per reset.  cluttered: n_goals = 1 for randomize_goal (0: goal at (size-2, size-2)),
-    n_clutter obstacles (lava with walls_are_lava); meetup: n_goals goal doors (1..3), n_clutter walls,
+    n_clutter obstacles (lava with walls_are_lava); meetup: n_goals goal doors (1..6), n_clutter walls,
     fully observed (`obs_full`, `obs_image` is None).
     fixed_spawn: [(x, y)] * n_agents start cells on a static map; fixed_mode 'always' = EmptyEnv's fixed start
     (empty.py:72-104), 'reset' = MazeEnv's (maze.py:86)."""

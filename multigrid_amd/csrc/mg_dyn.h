@@ -67,6 +67,7 @@ __host__ __device__ inline uint32_t kind_word(uint32_t k) {
 #endif
 constexpr int kCellB = 68;    // bytes per cell row: 64 lanes + 4 (bank spreading)
 constexpr int kCellW = 17;    // the same in dwords
+constexpr int kMaxGoals = 6; // MeetupEnv goal doors kept per env: aux words 0..2, two goals (x | y<<6, 0xFFFF = none) per word
 constexpr int kPreMax = 16;   // grid dwords per lane fetched per batch when a grid is not prefetched
 // PRE (template parameter of the kernels) = grid dwords per lane prefetched in registers: 16 covers grids up to 64
 // cells; the view-5 and the fully observed instantiations also exist with 64 (grids up to 16x16 — they have the
@@ -235,9 +236,10 @@ template <int A>
 __device__ __forceinline__ uint32_t meetup_dist(const Params& p, uint64_t pd, const uint32_t (&goal)[3], uint32_t& sum_out) {
   uint32_t best = 0, best_sum = 0xFFFFFFFFu;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < kMaxGoals; ++i) {
     if (i >= p.n_goals) continue;
-    const int gx = (int)(goal[i] & 63u), gy = (int)((goal[i] >> 6) & 63u);
+    const uint32_t gp = goal[i >> 1] >> (16 * (i & 1));              // two goals per aux word
+    const int gx = (int)(gp & 63u), gy = (int)((gp >> 6) & 63u);
     uint32_t sum = 0, bytes = 0;
 #pragma unroll
     for (int a = 0; a < A; ++a) {
@@ -369,7 +371,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   }
   uint32_t st = in.st[A];
   uint32_t carry = in.carry;
-  uint32_t goal[3] = {in.aux[0], in.aux[1], in.aux[2]};       // MEETUP: goal_pos[k] = x | y<<6
+  uint32_t goal[3] = {in.aux[0], in.aux[1], in.aux[2]};       // MEETUP: goal_pos[2k] | goal_pos[2k+1] << 16, each x | y<<6
   uint32_t past = in.aux[3];                                  // MEETUP: past_goal_dist, one byte per agent
   // agents (re)spawn at x < spawn_w: the DoorKey split (doorkey.py:77-78), the whole grid otherwise
   int spawn_w = p.kind != MG_KIND_DOORKEY ? p.W : (int)min((st >> 24) & 63u, (uint32_t)p.W);
@@ -525,19 +527,19 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       const uint32_t k2 = (p.kind == MG_KIND_CLUTTERED && (p.gen_flags & MG_GEN_LAVA)) ? K_LAVA : K_WALL;
       const int n_obj = p.n_goals + p.n_clutter;
       const bool inj = p.scatter != nullptr;
+      goal[0] = goal[1] = goal[2] = 0xFFFFFFFFu;
 #pragma unroll 1
       for (int i = 0; i < n_obj; ++i) {
         const uint32_t w = place_dyn<A>(p, g, pd, 0u, i, P_GEN, p.W, inj, inj ? (uint32_t)p.scatter[n * n_obj + i] : 0u, false, gid);
         gs(g_off(p, aw_x(w), aw_y(w)), i < p.n_goals ? k1 : k2);
         err |= w >> 16;
         if (i < p.n_goals) {                       // Meetup goal_pos[i]; Cluttered: the goal the shaper measures to
-          if (i == 0) goal[0] = w & AW_POS;
-          if (i == 1) goal[1] = w & AW_POS;
-          if (i == 2) goal[2] = w & AW_POS;
+          const uint32_t sh = 16u * (uint32_t)(i & 1), keep = ~(0xFFFFu << sh), v = (w & AW_POS) << sh;
+          if ((i >> 1) == 0) goal[0] = (goal[0] & keep) | v;
+          if ((i >> 1) == 1) goal[1] = (goal[1] & keep) | v;
+          if ((i >> 1) == 2) goal[2] = (goal[2] & keep) | v;
         }
       }
-#pragma unroll
-      for (int i = 0; i < 3; ++i) if (i >= p.n_goals) goal[i] = 0xFFFFFFFFu;
     }
     if (p.kind == MG_KIND_FOURROOMS) {
       // FourRoomsEnv._gen_grid (fourrooms.py:63-90): walls at x = W/2 and y = H/2 with one gap per segment, drawn
@@ -588,7 +590,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       const uint32_t w = place_dyn<A>(p, g, pd, all, 1, P_GEN, p.W, inj, inj ? (uint32_t)p.scatter[n * 3 + 2] : 0u, false, gid);
       gs(g_off(p, aw_x(w), aw_y(w)), K_GOAL);
       err |= w >> 16;
-      goal[0] = w & AW_POS; goal[1] = goal[2] = 0xFFFFFFFFu;
+      goal[0] = (w & AW_POS) | 0xFFFF0000u; goal[1] = goal[2] = 0xFFFFFFFFu;
     }
     if (p.kind == MG_KIND_MEETUP) {                                             // MeetupEnv.reset, meetup.py:59-62
       uint32_t sum;

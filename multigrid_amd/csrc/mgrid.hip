@@ -1107,8 +1107,8 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
       if (c.gen_n_clutter < 0 || c.gen_n_goals < 0 || c.gen_n_goals + c.gen_n_clutter > MG_MAX_SCATTER)
         return fail(MG_EINVAL, "gen_n_goals + gen_n_clutter must be in [0, 64]");
       if (c.env_kind == MG_KIND_CLUTTERED && c.gen_n_goals > 1) return fail(MG_EINVAL, "Cluttered has one goal: gen_n_goals is 0 or 1");
-      if (c.env_kind == MG_KIND_MEETUP && (c.gen_n_goals < 1 || c.gen_n_goals > 3))
-        return fail(MG_EUNSUPPORTED, "Meetup supports 1 to 3 goals");
+      if (c.env_kind == MG_KIND_MEETUP && (c.gen_n_goals < 1 || c.gen_n_goals > kMaxGoals))
+        return fail(MG_EUNSUPPORTED, "Meetup supports 1 to 6 goals");
       if (c.gen_n_goals + c.gen_n_clutter + 1 + c.n_agents > interior) return fail(MG_EINVAL, "more objects than interior cells");
     }
     var = nullptr;

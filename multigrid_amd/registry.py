@@ -95,7 +95,6 @@ register('MultiGrid-FourRooms-Single-v0', dict(kind='fourrooms', size=19, n_agen
                                                see_through_walls=False, competitive=False))
 
 # MeetupEnv family (multigrid_envs/meetup.py:26-236): fully observed, view size unused (default 7), max_steps 250.
-# MultiGrid-Meetup-Multi-12x12-v0 (5 goals) is not registered: the kernel keeps at most three goal doors.
 for _id, _size, _agents, _goals, _clutter in (('MultiGrid-Meetup-v0', 15, 3, 3, 0), ('MultiGrid-Meetup-Empty-6x6-v0', 6, 3, 3, 0),
                                              ('MultiGrid-Meetup-SingleTarget-6x6-Minigrid-v0', 6, 1, 1, 0),
                                              ('MultiGrid-Meetup-Empty-6x6-Minigrid-v0', 6, 1, 3, 0),
@@ -105,7 +104,7 @@ for _id, _size, _agents, _goals, _clutter in (('MultiGrid-Meetup-v0', 15, 3, 3, 
                                              ('MultiGrid-Meetup-Random-10x10-v0', 10, 3, 3, 10),
                                              ('MultiGrid-Meetup-Empty-12x12-v0', 12, 3, 3, 0), ('MultiGrid-Meetup-Empty-15x15-v0', 15, 3, 3, 0),
                                              ('MultiGrid-Meetup-Random-12x12-v0', 12, 3, 3, 10),
-                                             ('MultiGrid-Meetup-Single-12x12-v0', 12, 3, 1, 0)):
+                                             ('MultiGrid-Meetup-Single-12x12-v0', 12, 3, 1, 0), ('MultiGrid-Meetup-Multi-12x12-v0', 12, 3, 5, 0)):
   register(_id, dict(kind='meetup', size=_size, n_agents=_agents, view_size=7, max_steps=250, n_goals=_goals,
                      n_clutter=_clutter, see_through_walls=False, competitive=False, minigrid_mode='Minigrid' in _id))
 

@@ -88,7 +88,7 @@ void mgo_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
 enum { P_ORDER = 0, P_RESPAWN = 1, P_SPAWN = 2, P_ACTION = 3, P_GEN = 4, P_KEY = 5, P_OBJDROP = 6 };
 enum { KIND_STATIC = 0, KIND_DOORKEY = 1, KIND_CLUTTERED = 2, KIND_MEETUP = 3, KIND_FOURROOMS = 4 };
 #define MAXOBJ 64              /* objects a scatter generator places (goals/doors + clutter) */
-#define MAXGOALS 3
+#define MAXGOALS 6
 #define MAX_ATTEMPTS 256
 
 static uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
@@ -904,19 +904,24 @@ int mgo_last_scatter(const mgo_env* e, int8_t* out /* [MAXOBJ][2] */) {
   memcpy(out, e->last_scatter, (size_t)e->n_scatter * 2);
   return e->n_scatter;
 }
-/* kind-specific state in the product's packing (mg_buffers.aux, 4 words per env): words 0..2 = goal k
- * (x | y<<6, 0xFFFFFFFF if unused), word 3 = past_goal_dist, one byte per agent */
+/* kind-specific state in the product's packing (mg_buffers.aux, 4 words per env): words 0..2 = the goals, two per
+ * word (goal 2k in the low half of word k, goal 2k+1 in the high half, each x | y<<6, 0xFFFF if unused), word 3 =
+ * past_goal_dist, one byte per agent */
+static void aux_put_goal(uint32_t* out, int i, int x, int y) {
+  const uint32_t sh = 16u * (uint32_t)(i & 1);
+  out[i >> 1] = (out[i >> 1] & ~(0xFFFFu << sh)) | (((uint32_t)x | ((uint32_t)y << 6)) << sh);
+}
 void mgo_aux_words(const mgo_env* e, uint32_t* out /* [4] */) {
   for (int i = 0; i < 3; ++i) out[i] = 0xFFFFFFFFu;
   out[3] = 0;
   if (e->kind == KIND_MEETUP) {
-    for (int i = 0; i < e->n_goals; ++i) out[i] = (uint32_t)e->goal_x[i] | ((uint32_t)e->goal_y[i] << 6);
+    for (int i = 0; i < e->n_goals; ++i) aux_put_goal(out, i, e->goal_x[i], e->goal_y[i]);
     for (int a = 0; a < e->A && a < 4; ++a) out[3] |= (uint32_t)e->past_dist[a] << (8 * a);
   }
   if ((e->kind == KIND_CLUTTERED && e->n_goals) || e->kind == KIND_FOURROOMS) {   /* the scattered goal, which the v8 shaper measures to */
     int gx, gy;
     goal_position(e, &gx, &gy);
-    out[0] = (uint32_t)gx | ((uint32_t)gy << 6);
+    aux_put_goal(out, 0, gx, gy);
   }
 }
 /* what the last step/reset drew: order[A], respawn[A][4], spawn[A][4] */

@@ -52,7 +52,7 @@ def _cmp(env, orc, what, step=True):
 
 @pytest.mark.parametrize('size,A,goals,clutter,n,steps,max_steps', [(6, 3, 3, 0, 2000, 150, 40), (8, 3, 1, 5, 1500, 150, 50),
                                                                    (15, 3, 3, 0, 700, 120, 60), (10, 2, 2, 10, 500, 100, 45),
-                                                                   (12, 1, 3, 10, 300, 100, 45)])
+                                                                   (12, 1, 3, 10, 300, 100, 45), (12, 3, 5, 0, 600, 100, 45), (7, 2, 6, 3, 600, 100, 30)])
 def test_meetup_free_running_parity(size, A, goals, clutter, n, steps, max_steps):
   _need_gpu()
   env, orc = _make('meetup', size, A, n, max_steps, seed=size + goals, V=7, n_goals=goals, n_clutter=clutter)

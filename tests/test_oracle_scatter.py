@@ -30,7 +30,7 @@ def test_meetup_known_answers():
   assert tuple(img[2, 1]) == (10, 0, 0) and tuple(img[3, 4]) == (10, 1, 2) and tuple(img[2, 2]) == (1, 0, 0)
   # goal 0: |1-2|+0 + |1-3|+|1-4| = 1 + 5 = 6; goal 1: 2+3 + 1+0 = 6 -> tie, argmin takes goal 0
   aux = env.aux_words()
-  assert aux[0] == 1 | 1 << 6 and aux[1] == 4 | 4 << 6 and aux[2] == 0xFFFFFFFF
+  assert aux[0] == (1 | 1 << 6) | (4 | 4 << 6) << 16 and aux[1] == 0xFFFFFFFF and aux[2] == 0xFFFFFFFF
   assert aux[3] == 1 | 5 << 8
   # agent 1 steps west to (2,4): goal 0 sum = 1 + (1+3) = 5, goal 1 sum = 5 + 2 = 7 -> goal 0; reward = 5 - 4
   _, rew, done, _ = env.step([6, 2], order=[0, 1], respawn=[(-1, -1, 0)] * 2)
@@ -124,7 +124,7 @@ def test_fourrooms_known_layout():
     assert tuple(g[7, k]) == want_h, k
   assert tuple(g[13, 13]) == (8, 1, 0)
   assert int((g[:, :, 0] == 2).sum()) == 56 + 13 + 13 - 1 - 3     # border + two walls (sharing (7,7)) - three gaps
-  assert env.aux_words()[0] == 13 | 13 << 6
+  assert env.aux_words()[0] == (13 | 13 << 6) | 0xFFFF0000
 
 
 def test_two_rooms_known_layouts():
@@ -210,6 +210,12 @@ def test_two_rooms_cross():
 def test_meetup_cross_6x6():
   ev = _cross('meetup', 6, 3, 3000, seed=2, max_steps=60, n_goals=3, n_clutter=0)
   assert ev['episodes'] > 20 and ev['reward'] > 200 and ev['early'] > 0, ev
+
+
+def test_meetup_cross_five_goals():
+  """MultiMeetupEnv12x12's shape (meetup.py:173-176) on a smaller grid, so that meetings still happen"""
+  ev = _cross('meetup', 7, 3, 2500, seed=8, max_steps=60, n_goals=5, n_clutter=0)
+  assert ev['episodes'] > 20 and ev['reward'] > 100, ev
 
 
 def test_meetup_cross_8x8_clutter_single_goal():
