@@ -38,6 +38,11 @@
 extern "C" {
 #endif
 
+/* bytes per env of the action and order buffers: one dword up to four agents, two dwords for five (the reference's
+ * Empty-16x16, FourRooms-v0 and DoorKey-16x16 ids) */
+#define MG_MAX_AGENTS 5
+#define MG_SLOTS(n_agents) ((n_agents) <= 4 ? 4 : 8)
+
 #define MG_OK            0
 #define MG_EINVAL       -1  /* bad argument / config */
 #define MG_EHIP         -2  /* HIP runtime error (text in mg_last_error) */
@@ -223,12 +228,12 @@ int mg_reset_inject(mg_handle* h, const uint8_t* env_mask, const int8_t* spawn);
 
 /* env.step(actions) (multigrid.py:963-995) for all envs, free-running: the agent order
  * (multigrid.py:973-974) and respawns (multigrid.py:815-832) are drawn on device (Philox).
- * actions = device pointer uint8[env_stride][4]: byte a of env n = action of agent a in [0,6]
+ * actions = device pointer uint8[env_stride][MG_SLOTS(n_agents)]: byte a of env n = action of agent a in [0,6]
  * (the list `env.step(actions)` takes, multigrid.py:963-978); bytes >= A are ignored. */
 int mg_step(mg_handle* h, const void* actions);
 
 /* env.step(actions) with the reference's two RNG streams injected (bit-exact replay):
- *   order   = device uint8[env_stride][4]: byte k of env n = agent acting k-th (the shuffled
+ *   order   = device uint8[env_stride][MG_SLOTS(n_agents)]: byte k of env n = agent acting k-th (the shuffled
  *             np.arange of multigrid.py:973-974)
  *   respawn = device int8[env_stride][A][4] = (x,y,dir,0) accepted by place_one_agent for
  *             agent a if it finishes this step (multigrid.py:832), x = -1 if none recorded
@@ -258,7 +263,7 @@ int mg_export_grid(mg_handle* h, uint8_t* out);
 
 /* Synthetic-rollout step: like mg_step but the actions are drawn on device too
  * (uniform in [0,6], the "random actions" of BASELINE.json configs) and also stored to
- * `actions_out` (device uint8[env_stride][4], same layout as `actions`; may be NULL). */
+ * `actions_out` (device uint8[env_stride][MG_SLOTS(n_agents)], same layout as `actions`; may be NULL). */
 int mg_step_random(mg_handle* h, uint8_t* actions_out);
 
 int mg_get_buffers(mg_handle* h, mg_buffers* out);

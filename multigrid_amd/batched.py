@@ -103,9 +103,10 @@ class BatchedMultiGrid:
       self.grid_words = int(b.grid_words)
       self.carry = _alias(b.carry, (S,), '<i4', dev)[:n]                        # byte a = kind agent a carries
       self.grid_blocked = _alias(b.grid, (S // 64, self.grid_words * 4, 64), '|u1', dev)  # [chunk][cell][lane], include/mgrid.h
-    # action buffer in the layout the kernel reads: one dword per env, byte a = agent a's action.
-    # Policies write `env.actions[:N, a]`; `step()` with no argument consumes it.
-    self.actions = torch.full((S, 4), 6, dtype=torch.uint8, device=dev)
+    # action buffer in the layout the kernel reads: one dword per env (two with five agents), byte a = agent a's
+    # action.  Policies write `env.actions[:N, a]`; `step()` with no argument consumes it.
+    self.slots = _lib.slots(A)
+    self.actions = torch.full((S, self.slots), 6, dtype=torch.uint8, device=dev)
     gx, gy = C.c_int32(), C.c_int32()
     _lib.check(self.L.mg_get_goal(self.h, C.byref(gx), C.byref(gy)))
     self.goal_pos = (gx.value, gy.value)
@@ -152,7 +153,7 @@ class BatchedMultiGrid:
     t = torch.as_tensor(actions, device=self.device)
     if t.dtype != torch.uint8:
       t = t.clamp(0, 255).to(torch.uint8)     # anything outside [0,6] is reported as MG_ERR_BAD_ACTION
-    return self._env_major(t, torch.uint8, 4)
+    return self._env_major(t, torch.uint8, self.slots)
 
   def obs(self):
     if self.obs_full is not None:      # fully_observed (multigrid.py:1043-1065)
@@ -233,7 +234,7 @@ class BatchedMultiGrid:
     return self.obs()
 
   def step(self, actions=None):
-    """env.step(actions): actions uint8 [stride, 4] (kernel layout, zero copy), or agent-major
+    """env.step(actions): actions uint8 [stride, slots] (kernel layout, zero copy; slots = 4, or 8 with five agents), or agent-major
     [A, N] of any integer dtype (copied), or None to consume the preloaded self.actions."""
     if actions is None:
       ap, _a = C.c_void_p(self.actions.data_ptr()), self.actions
@@ -244,7 +245,7 @@ class BatchedMultiGrid:
 
   def step_replay(self, actions, order, respawn, reset_spawn=None, objdrop=None, reset_gen=None):
     ap, _a = self._actions_ptr(actions)
-    op, _o = self._env_major(order, torch.uint8, 4)
+    op, _o = self._env_major(order, torch.uint8, self.slots)
     rp, _r = self._env_major(respawn, torch.int8, self.n_agents, (4,))
     sp, _s = self._env_major(reset_spawn, torch.int8, self.n_agents, (4,))
     if self.mutable_grid:
@@ -259,7 +260,7 @@ class BatchedMultiGrid:
     """One step with on-device uniform random actions (synthetic rollouts)."""
     ptr = None
     if actions_out is not None:
-      assert actions_out.dtype == torch.uint8 and tuple(actions_out.shape) == (self.stride, 4)
+      assert actions_out.dtype == torch.uint8 and tuple(actions_out.shape) == (self.stride, self.slots)
       ptr = C.c_void_p(actions_out.data_ptr())
     _lib.check(self.L.mg_step_random(self.h, ptr))
     return self.obs(), self.reward, self.done, {}

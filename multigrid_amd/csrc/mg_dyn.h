@@ -79,7 +79,7 @@ __device__ __forceinline__ void g_set(uint8_t* gl, int off, uint32_t k) { gl[off
 
 // place_obj's acceptance test (multigrid.py:603-613) inside x < xmax on this env's own grid
 template <int A>
-__device__ __forceinline__ bool dyn_free(const Params& p, const uint8_t* g, uint64_t pd, uint32_t occ, int x, int y, int xmax) {
+__device__ __forceinline__ bool dyn_free(const Params& p, const uint8_t* g, pd_t<A> pd, uint32_t occ, int x, int y, int xmax) {
   if ((unsigned)x >= (unsigned)min(xmax, p.W) || (unsigned)y >= (unsigned)p.H) return false;
   if (g_get(g, g_off(p, x, y)) != 0u) return false;
   const uint32_t pos = (uint32_t)x | ((uint32_t)y << 6);
@@ -93,7 +93,7 @@ __device__ __forceinline__ bool dyn_free(const Params& p, const uint8_t* g, uint
 // object, in the rectangle x < xmax.  Injected draw (have_inj, injw = int8x4 x,y,dir,0) or Philox
 // rejection sampling keyed (purpose, a, attempt).  Returns x | y<<6 | dir<<12 | MG_ERR_*<<16.
 template <int A>
-__device__ __forceinline__ uint32_t place_dyn(const Params& p, const uint8_t* g, uint64_t pd, uint32_t occ, int a,
+__device__ __forceinline__ uint32_t place_dyn(const Params& p, const uint8_t* g, pd_t<A> pd, uint32_t occ, int a,
                                               int purpose, int xmax, bool have_inj, uint32_t injw, bool is_agent,
                                               uint32_t gid) {
   int x = -1, y = -1, dir = 0;
@@ -233,7 +233,7 @@ __device__ __forceinline__ void dyn_wait(DynIn<A, PRE>& in) {
 // MeetupEnv.get_dist (meetup.py:78-84): Manhattan distance of every agent to the goal whose summed
 // distance over the agents is smallest (np.argmin: the first such goal).  Returns one byte per agent.
 template <int A>
-__device__ __forceinline__ uint32_t meetup_dist(const Params& p, uint64_t pd, const uint32_t (&goal)[3], uint32_t& sum_out) {
+__device__ __forceinline__ uint32_t meetup_dist(const Params& p, pd_t<A> pd, const uint32_t (&goal)[3], uint32_t& sum_out) {
   uint32_t best = 0, best_sum = 0xFFFFFFFFu;
 #pragma unroll
   for (int i = 0; i < kMaxGoals; ++i) {
@@ -262,7 +262,7 @@ __device__ __forceinline__ uint32_t meetup_dist(const Params& p, uint64_t pd, co
 // K_AGENT0 + 4*id + dir); the next chunk's copy-in overwrites every interior cell, so they never leak.
 template <int A>
 __device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uint8_t* gwave, const uint32_t* lut,
-                                          const uint16_t* cpc, uint64_t pd, int lane, uint8_t* gchunk) {
+                                          const uint16_t* cpc, pd_t<A> pd, int lane, uint8_t* gchunk) {
   const int cells = p.W * p.H, FB = cells * 3;
 #pragma unroll
   for (int b = 0; b < A; ++b) {
@@ -359,14 +359,14 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   bool dirty = false;            // this env's grid changed: the wave's rows go back to HBM only if some lane's did
   auto gs = [&](int off, uint32_t k) { g_set(g, off, k); dirty = true; };
 
-  uint64_t pd = 0;
+  pd_t<A> pd = pd_t<A>{};
   uint32_t shw[A];
   uint32_t actw = 0, err = 0;
 #pragma unroll
   for (int a = 0; a < A; ++a) {
     const uint32_t w = in.st[a];
     const uint32_t cx = min(w & 63u, (uint32_t)(p.W - 1)), cy = min((w >> 6) & 63u, (uint32_t)(p.H - 1));
-    pd |= (uint64_t)(cx | (cy << 6) | (w & 0x3000u)) << (14 * a);
+    pd = pd_set(pd, a, cx | (cy << 6) | (w & 0x3000u));
     shw[a] = w & ~AW_POSDIR;
   }
   uint32_t st = in.st[A];
@@ -392,7 +392,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     uint32_t gbits = 0;
 #pragma unroll 1
     for (int k = 0; k < A; ++k) {                                               // step_one_agent, multigrid.py:860-904
-      const int a = (int)((ordw >> (2 * k)) & 3u);
+      const int a = (int)((ordw >> (kOrdBits<A> * k)) & ((1u << kOrdBits<A>) - 1u));
       const uint32_t s = pd_get(pd, a);
       const uint32_t act = (actw >> (3 * a)) & 7u;
       const int x = aw_x(s), y = aw_y(s), d = aw_d(s);

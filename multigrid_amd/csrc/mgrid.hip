@@ -97,6 +97,7 @@ struct Params {
   int32_t gx, gy, LW, LH;      // shaper goal and the dims of the mutable-grid kernel's |dx|,|dy| distance LUT
   int32_t fixed_mode, fixed_pad;   // MG_FIXED_*: agents (re)start on fixed cells (shared-map kernels)
   uint64_t fixed_pd;           // their start cells, packed like pd (x | y<<6 per agent, 14 bits each)
+  uint32_t fixed_pd_hi, reserved_pd;   // the fifth agent's (five agents do not fit one u64)
   const uint16_t* scatter;     // int8x2 per (env, scattered object): injected layout draws
   uint32_t* aux;               // [stride][4]  MEETUP goal positions + past distances
   uint8_t* obs_full;           // [stride][W*H*3]  fully observed obs
@@ -137,11 +138,23 @@ __device__ __forceinline__ uint32_t pd_get(uint64_t pd, int a) { return (uint32_
 __device__ __forceinline__ uint64_t pd_set(uint64_t pd, int a, uint32_t v) {
   return (pd & ~((uint64_t)AW_POSDIR << (14 * a))) | ((uint64_t)v << (14 * a));
 }
+// Five agents (Empty-16x16, FourRooms-v0, DoorKey-16x16) need 70 bits: the fifth agent's word rides in a second
+// register.  pd_t<A> is the plain u64 for A <= 4, so those kernels compile exactly as before.
+struct Pd5 { uint64_t lo; uint32_t hi; };
+__device__ __forceinline__ uint32_t pd_get(const Pd5& pd, int a) { return a < 4 ? pd_get(pd.lo, a) : (pd.hi & AW_POSDIR); }
+__device__ __forceinline__ Pd5 pd_set(Pd5 pd, int a, uint32_t v) {
+  if (a < 4) pd.lo = pd_set(pd.lo, a, v); else pd.hi = v;
+  return pd;
+}
+template <int A> struct PdOf { typedef uint64_t type; };
+template <> struct PdOf<5> { typedef Pd5 type; };
+template <int A> using pd_t = typename PdOf<A>::type;
+constexpr int kMaxAgents = 5;
 
 // place_obj's acceptance test (multigrid.py:603-613) on the shared static map.
 // occ = bit mask of agents whose position currently counts (agent_pos not None).
 template <int A>
-__device__ __forceinline__ bool cell_free(const Params& p, const uint32_t* map, uint64_t pd,
+__device__ __forceinline__ bool cell_free(const Params& p, const uint32_t* map, pd_t<A> pd,
                                           uint32_t occ, int x, int y) {
   if ((unsigned)x >= (unsigned)p.W || (unsigned)y >= (unsigned)p.H) return false;
   const int pad = (p.PW - p.W) >> 1;
@@ -157,7 +170,7 @@ __device__ __forceinline__ bool cell_free(const Params& p, const uint32_t* map, 
 // MG_ERR_* bits (if any) in bits 16+.  inj != nullptr: the draw the reference accepted is
 // injected (int8x4 = x, y, dir, 0).  Rare path (goal touch, reset).
 template <int A>
-__device__ __forceinline__ uint32_t place_agent(const Params& p, const uint32_t* map, uint64_t pd, uint32_t occ,
+__device__ __forceinline__ uint32_t place_agent(const Params& p, const uint32_t* map, pd_t<A> pd, uint32_t occ,
                                                 int a, int purpose, const uint32_t* inj, int64_t n, uint32_t gid) {
   int x = -1, y = -1, dir = 0;
   uint32_t err = 0;
@@ -283,7 +296,7 @@ __device__ __forceinline__ void table_view(const Params& p, const uint32_t* tabl
 
 // Stage the 64 images of this wave in LDS and stream them to HBM as one contiguous chunk.
 template <int A, int V>
-__device__ __forceinline__ void emit_obs(uint64_t pd, int a, uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t vm,
+__device__ __forceinline__ void emit_obs(pd_t<A> pd, int a, uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t vm,
                                          uint32_t* stage, int lane, uint8_t* gchunk) {
   constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
   const uint32_t me = pd_get(pd, a);
@@ -354,12 +367,15 @@ __device__ __forceinline__ void emit_obs(uint64_t pd, int a, uint32_t (&s)[ViewG
 // s_waitcnt vmcnt(K) issued after >= K younger stores retires these loads without waiting for
 // those stores (wait_chunk).  Nothing is computed from the registers before that wait.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// action / order slots per env: four bytes (one dword) up to four agents, eight bytes for five
+template <int A> constexpr int kSlotWords = A > 4 ? 2 : 1;
 struct ChunkIn {
   u32x4 q;                       // A == 3: the four env_state words
-  uint32_t w0, w1, w2, w3, w4;   // other A: env_state words (scalars, not an array: an array member made hipcc keep the
+  uint32_t w0, w1, w2, w3, w4, w5;   // other A: env_state words (scalars, not an array: an array member made hipcc keep the
                                  // launch-resident batch's ChunkIn[] in scratch and store the registers there while
                                  // their loads were still in flight — tools/isa_prefetch_lint.py)
   uint32_t act;                  // the env's four action bytes, as loaded
+  uint32_t act2;                 // five agents: action bytes 4..7 (the action / order slots are 8 bytes per env then)
 };
 
 __device__ __forceinline__ uint32_t asm_load_u32(const void* ptr) {
@@ -373,8 +389,8 @@ __device__ __forceinline__ uint32_t asm_load_u32(const void* ptr) {
 // else (reset, replay, step_random, emit_env_reward) runs the general instantiation.
 __device__ __forceinline__ void zero_chunk(ChunkIn& in) {
   in.q = u32x4{0, 0, 0, 0};
-  in.w0 = in.w1 = in.w2 = in.w3 = in.w4 = 0u;
-  in.act = 0x06060606u;
+  in.w0 = in.w1 = in.w2 = in.w3 = in.w4 = in.w5 = 0u;
+  in.act = in.act2 = 0x06060606u;
 }
 
 template <int A, bool FAST>
@@ -391,17 +407,21 @@ __device__ __forceinline__ void load_chunk(const Params& p, int64_t env0, int la
     if (A >= 2) in.w2 = asm_load_u32(sp + 2);
     if (A >= 3) in.w3 = asm_load_u32(sp + 3);
     if (A >= 4) in.w4 = asm_load_u32(sp + 4);
+    if (A >= 5) in.w5 = asm_load_u32(sp + 5);
   }
-  if (FAST || (p.op == OP_STEP && !p.random_actions)) in.act = asm_load_u32(p.actions + n);
+  if (FAST || (p.op == OP_STEP && !p.random_actions)) {
+    in.act = asm_load_u32(p.actions + n * kSlotWords<A>);
+    if (A > 4) in.act2 = asm_load_u32(p.actions + n * kSlotWords<A> + 1);
+  }
 }
 
 // Retire the loads of load_chunk: at most K vector-memory operations younger than them may stay
 // in flight.  The registers are operands so that no use (not even a copy) can be moved above it.
 template <int K>
 __device__ __forceinline__ void wait_chunk(ChunkIn& in) {
-  asm volatile("s_waitcnt vmcnt(%7)"
-               : "+v"(in.q), "+v"(in.w0), "+v"(in.w1), "+v"(in.w2), "+v"(in.w3), "+v"(in.w4),
-                 "+v"(in.act)
+  asm volatile("s_waitcnt vmcnt(%9)"
+               : "+v"(in.q), "+v"(in.w0), "+v"(in.w1), "+v"(in.w2), "+v"(in.w3), "+v"(in.w4), "+v"(in.w5),
+                 "+v"(in.act), "+v"(in.act2)
                : "n"(K)
                : "memory");
 }
@@ -414,31 +434,39 @@ __device__ __forceinline__ uint32_t draw_actions(const Params& p, int64_t n, uin
   const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
   uint32_t actw = 0;
 #pragma unroll
-  for (int a = 0; a < A; ++a) actw |= __umulhi(rr[a & 3], 7u) << (3 * a);
+  for (int a = 0; a < A && a < 4; ++a) actw |= __umulhi(rr[a], 7u) << (3 * a);
+  if (A > 4) {   // a second draw (counter word + 1) for the fifth agent
+    const U4 r2 = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), ((uint32_t)P_ACTION << 28) | 1u, p.seed_lo, p.seed_hi);
+    actw |= __umulhi(r2.x, 7u) << 12;
+  }
   if (p.actions_out && active) {
     uint32_t w = 0;
 #pragma unroll
-    for (int a = 0; a < A; ++a) w |= ((actw >> (3 * a)) & 7u) << (8 * a);
-    p.actions_out[n] = w;
+    for (int a = 0; a < A && a < 4; ++a) w |= ((actw >> (3 * a)) & 7u) << (8 * a);
+    p.actions_out[n * kSlotWords<A>] = w;
+    if (A > 4) p.actions_out[n * kSlotWords<A> + 1] = (actw >> 12) & 7u;
   }
   return actw;
 }
 
-// Agent order of this step (multigrid.py:973-974), packed 2 bits per slot: injected, or a
-// Philox Fisher-Yates.
+// Agent order of this step (multigrid.py:973-974), packed kOrdBits<A> bits per slot (2; 3 for five agents):
+// injected, or a Philox Fisher-Yates.
+template <int A> constexpr int kOrdBits = A > 4 ? 3 : 2;
 template <int A, bool FAST>
 __device__ __forceinline__ uint32_t agent_order(const Params& p, int64_t n, uint32_t gid, bool active, uint32_t& err) {
+  constexpr int OB = kOrdBits<A>;
+  constexpr uint32_t OM = (1u << OB) - 1u;
   uint32_t ordw = 0;
 #pragma unroll
-  for (int k = 0; k < A; ++k) ordw |= (uint32_t)k << (2 * k);
+  for (int k = 0; k < A; ++k) ordw |= (uint32_t)k << (OB * k);
   if (!FAST && p.order) {
     uint32_t seen = 0, w = 0;
-    const uint32_t ow = p.order[n];
+    const uint32_t ow = p.order[n * kSlotWords<A>], ow2 = A > 4 ? p.order[n * kSlotWords<A> + 1] : 0u;
 #pragma unroll
     for (int k = 0; k < A; ++k) {
-      const uint32_t o = (ow >> (8 * k)) & 255u;
+      const uint32_t o = ((k < 4 ? ow >> (8 * k) : ow2 >> (8 * (k - 4)))) & 255u;
       if (o < (uint32_t)A) seen |= 1u << o;
-      w |= (o & 3u) << (2 * k);
+      w |= (o & OM) << (OB * k);
     }
     if (seen != (1u << A) - 1u) { if (active) err |= MG_ERR_BAD_ORDER; }
     else ordw = w;
@@ -449,9 +477,9 @@ __device__ __forceinline__ uint32_t agent_order(const Params& p, int64_t n, uint
 #pragma unroll
     for (int i = A - 1, w = 0; i >= 1; --i, ++w) {
       const uint32_t j = __umulhi(rr[w & 3], (uint32_t)(i + 1));
-      const uint32_t oi = (ordw >> (2 * i)) & 3u, oj = (ordw >> (2 * j)) & 3u;
-      ordw = (ordw & ~(3u << (2 * i)) & ~(3u << (2 * j))) | (oi << (2 * j));
-      ordw = (ordw & ~(3u << (2 * i))) | (oj << (2 * i));
+      const uint32_t oi = (ordw >> (OB * i)) & OM, oj = (ordw >> (OB * j)) & OM;
+      ordw = (ordw & ~(OM << (OB * i)) & ~(OM << (OB * j))) | (oi << (OB * j));
+      ordw = (ordw & ~(OM << (OB * i))) | (oj << (OB * i));
     }
   }
   return ordw;
@@ -504,12 +532,16 @@ __device__ __forceinline__ uint32_t v8_shape(const Params& p, const double* dist
 // EmptyEnv.place_one_agent with agent_start='fixed' (multigrid_envs/empty.py:72-104): agent a goes to its start cell
 // facing east; whoever stands there is sent back to its own start cell first, and so on down the chain.  on_grid =
 // agents that currently have a cell (the finishing agent was taken off the grid before, multigrid.py:817-819).
+__device__ __forceinline__ uint32_t fixed_start(const Params& p, int a) {   // start cell of agent a (x | y<<6)
+  return (a < 4 ? pd_get(p.fixed_pd, a) : p.fixed_pd_hi) & AW_POS;
+}
+
 template <int A>
-__device__ __forceinline__ uint64_t fixed_place(const Params& p, uint64_t pd, int a, uint32_t on_grid) {
+__device__ __forceinline__ pd_t<A> fixed_place(const Params& p, pd_t<A> pd, int a, uint32_t on_grid) {
   int t = a;
 #pragma unroll 1
   for (int it = 0; it < A; ++it) {
-    const uint32_t spos = pd_get(p.fixed_pd, t) & AW_POS;
+    const uint32_t spos = fixed_start(p, t);
     int b = -1;
 #pragma unroll
     for (int c = 0; c < A; ++c)
@@ -533,21 +565,21 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
   const uint32_t gid = (uint32_t)(p.gid_base + (uint64_t)n);
   const int pad = (p.PW - p.W) >> 1;
 
-  uint64_t pd = 0;              // x | y<<6 | dir<<12 of every agent, 14 bits each
+  pd_t<A> pd = pd_t<A>{};       // x | y<<6 | dir<<12 of every agent, 14 bits each
   uint32_t shw[A];              // v8 shaper bits of each agent word (bits 14..29)
-  uint32_t win[5];
-  if (A == 3) { win[0] = in.q.x; win[1] = in.q.y; win[2] = in.q.z; win[3] = in.q.w; win[4] = 0u; }
+  uint32_t win[6];
+  if (A == 3) { win[0] = in.q.x; win[1] = in.q.y; win[2] = in.q.z; win[3] = in.q.w; win[4] = 0u; win[5] = 0u; }
   else {
-    win[0] = in.w0; win[1] = in.w1; win[2] = in.w2; win[3] = in.w3; win[4] = in.w4;
+    win[0] = in.w0; win[1] = in.w1; win[2] = in.w2; win[3] = in.w3; win[4] = in.w4; win[5] = in.w5;
   }
   uint32_t actw = 0, st = win[A], err = 0;
 #pragma unroll
   for (int a = 0; a < A; ++a) {
-    actw |= min((in.act >> (8 * a)) & 255u, 7u) << (3 * a);
+    actw |= min(((a < 4 ? in.act >> (8 * a) : in.act2 >> (8 * (a - 4)))) & 255u, 7u) << (3 * a);
     // keep every later LDS index in range whatever the buffer holds
     const uint32_t w = win[a];
     const uint32_t cx = min(w & 63u, (uint32_t)(p.W - 1)), cy = min((w >> 6) & 63u, (uint32_t)(p.H - 1));
-    pd |= (uint64_t)(cx | (cy << 6) | (w & 0x3000u)) << (14 * a);
+    pd = pd_set(pd, a, cx | (cy << 6) | (w & 0x3000u));
     shw[a] = w & ~AW_POSDIR;
   }
   uint32_t done_flag = 0;
@@ -570,7 +602,7 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
     uint32_t gbits = 0;          // agents whose forward touched the goal this step
 #pragma unroll 1
     for (int k = 0; k < A; ++k) {
-      const int a = (int)((ordw >> (2 * k)) & 3u);
+      const int a = (int)((ordw >> (kOrdBits<A> * k)) & ((1u << kOrdBits<A>) - 1u));
       const uint32_t s = pd_get(pd, a);
       const uint32_t act = (actw >> (3 * a)) & 7u;
       const int x = aw_x(s), y = aw_y(s), d = aw_d(s);
@@ -640,7 +672,7 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
       } else if (p.fixed_mode == MG_FIXED_AT_RESET) {       // MazeEnv: place_agent_at_pos(start_pos), direction drawn (maze.py:86)
         const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), ((uint32_t)P_SPAWN << 28) | ((uint32_t)a << 20),
                             p.seed_lo, p.seed_hi);
-        pd = pd_set(pd, a, (pd_get(p.fixed_pd, a) & AW_POS) | ((r.z >> 30) << 12));
+        pd = pd_set(pd, a, fixed_start(p, a) | ((r.z >> 30) << 12));
       } else {
         const uint32_t w = place_agent<A>(p, map, pd, (1u << a) - 1u, a, P_SPAWN, inj_spawn, n, gid);
         pd = pd_set(pd, a, w & AW_POSDIR);
@@ -788,7 +820,7 @@ struct Variant { int A, V; kernel_fn generic[2], table[2]; int entw; };
                               {mg_kernel<A, V, true, false>, mg_kernel<A, V, true, true>}, ViewGeom<V>::ENTW}
 #define MG_VARIANT_GEN(A, V) {A, V, {mg_kernel<A, V, false, false>, mg_kernel<A, V, false, true>}, {nullptr, nullptr}, 0}
 const Variant kVariants[] = {
-    MG_VARIANT_TAB(1, 5), MG_VARIANT_TAB(2, 5), MG_VARIANT_TAB(3, 5), MG_VARIANT_TAB(4, 5), MG_VARIANT_TAB(3, 3),
+    MG_VARIANT_TAB(1, 5), MG_VARIANT_TAB(2, 5), MG_VARIANT_TAB(3, 5), MG_VARIANT_TAB(4, 5), MG_VARIANT_TAB(5, 5), MG_VARIANT_TAB(3, 3),
     MG_VARIANT_GEN(1, 7), MG_VARIANT_GEN(2, 7), MG_VARIANT_GEN(3, 7),
 };
 
@@ -886,7 +918,7 @@ struct mg_handle {
   uint8_t* obs_full;
   bool full_obs;
   int dyn_waves_cu;      // waves of the mutable-grid kernel a CU can hold by registers
-  int fixed_mode; uint64_t fixed_pd;       // mg_set_fixed_spawn
+  int fixed_mode; uint64_t fixed_pd; uint32_t fixed_pd_hi;       // mg_set_fixed_spawn
   std::vector<uint8_t> free_cells;         // host copy: cell (y*W + x) holds nothing (placement checks)
   int LW, LH;            // dims of the mutable-grid kernel's relative distance LUT
   mg_buffers buf;
@@ -1000,7 +1032,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   p.carry = h->carry; p.grid = h->grid;
   p.n_goals = c.gen_n_goals; p.n_clutter = c.gen_n_clutter; p.gen_flags = c.gen_flags; p.full_obs = h->full_obs ? 1 : 0;
   p.gx = h->gx; p.gy = h->gy; p.LW = h->LW; p.LH = h->LH;
-  p.fixed_mode = h->fixed_mode; p.fixed_pd = h->fixed_pd;
+  p.fixed_mode = h->fixed_mode; p.fixed_pd = h->fixed_pd; p.fixed_pd_hi = h->fixed_pd_hi; p.reserved_pd = 0;
   p.scatter = reinterpret_cast<const uint16_t*>(scatter); p.aux = h->aux; p.obs_full = h->obs_full;
   int nw; unsigned grid; size_t lds;
   DeviceGuard g(h->device);
@@ -1125,7 +1157,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   h->dynamic = false; h->dvar = dvar; h->GW = (c.width * c.height + 3) / 4;
   h->base_grid = nullptr; h->carry = nullptr; h->grid = nullptr; h->aux = nullptr; h->obs_full = nullptr;
   h->full_obs = c.env_kind == MG_KIND_MEETUP; h->LW = c.width; h->LH = c.height;
-  h->dyn_waves_cu = 8; h->fixed_mode = 0; h->fixed_pd = 0;
+  h->dyn_waves_cu = 8; h->fixed_mode = 0; h->fixed_pd = 0; h->fixed_pd_hi = 0;
   if (dvar) {
     hipFuncAttributes fa;
     if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(dvar->fn)) == hipSuccess && fa.numRegs > 0) {
@@ -1327,14 +1359,16 @@ int mg_set_fixed_spawn(mg_handle* h, const int8_t* xy, int mode) {
   if (h->dynamic) return fail(MG_EUNSUPPORTED, "fixed start cells are not implemented for mutable grids");
   const int W = h->cfg.width, H = h->cfg.height, A = h->cfg.n_agents;
   uint64_t pd = 0;
+  uint32_t pd_hi = 0;
   for (int a = 0; a < A; ++a) {
     const int x = xy[2 * a], y = xy[2 * a + 1];
     if (x < 0 || y < 0 || x >= W || y >= H || !h->free_cells[(size_t)y * W + x]) return fail(MG_EINVAL, "start cell is not a free cell of the map");
     for (int b = 0; b < a; ++b)
       if (xy[2 * b] == x && xy[2 * b + 1] == y) return fail(MG_EINVAL, "two agents share a start cell");
-    pd |= (uint64_t)((uint32_t)x | ((uint32_t)y << 6)) << (14 * a);
+    const uint32_t w = (uint32_t)x | ((uint32_t)y << 6);
+    if (a < 4) pd |= (uint64_t)w << (14 * a); else pd_hi = w;
   }
-  h->fixed_pd = pd; h->fixed_mode = mode; h->have_reset = false;
+  h->fixed_pd = pd; h->fixed_pd_hi = pd_hi; h->fixed_mode = mode; h->have_reset = false;
   return MG_OK;
 }
 

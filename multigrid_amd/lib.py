@@ -17,6 +17,11 @@ GEN_TWO_ROOMS = 2
 FIXED_OFF, FIXED_ALWAYS, FIXED_AT_RESET = 0, 1, 2
 
 
+def slots(n_agents):
+  """MG_SLOTS(n_agents): bytes per env of the action / order buffers (include/mgrid.h)"""
+  return 4 if n_agents <= 4 else 8
+
+
 def kind_id(type_, color=0, state=0):
   """MG_KIND_ID (include/mgrid.h): one-byte cell kind of the mutable per-env grids."""
   if type_ in (0, 1, 10):

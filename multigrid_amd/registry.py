@@ -40,13 +40,14 @@ register('MultiGrid-Cluttered-Fixed-Single-6x6-v0', dict(
 
 # EmptyEnv with agent_start='random' (multigrid_envs/empty.py:28-60, 106-117): border walls, goal at (size-2, size-2),
 # agents anywhere, view 5, see_through_walls=True, max_steps 2*size^2 — a static layout.
-for _id, _size, _agents in (('MultiGrid-Empty-Random-5x5-v0', 5, 2), ('MultiGrid-Empty-Random-8x8-v0', 8, 3)):
+for _id, _size, _agents in (('MultiGrid-Empty-Random-5x5-v0', 5, 2), ('MultiGrid-Empty-Random-8x8-v0', 8, 3),
+                            ('MultiGrid-Empty-Random-16x16-v0', 16, 5)):
   register(_id, dict(layout=(lambda n=_size: layouts.empty_bordered(n, n, goal=(n - 2, n - 2))), n_agents=_agents, view_size=5,
                      max_steps=2 * _size * _size, see_through_walls=True, competitive=False))
 
 # EmptyEnv with the default agent_start='fixed' (empty.py:28-36, 72-104): agents (re)start on (1, 1+i) facing east.
-# The 16x16 id has five agents (not instantiated).
-for _id, _size, _agents in (('MultiGrid-Empty-5x5-v0', 5, 2), ('MultiGrid-Empty-8x8-v0', 8, 3), ('MultiGrid-Empty-5x5-Single-v0', 5, 1)):
+for _id, _size, _agents in (('MultiGrid-Empty-5x5-v0', 5, 2), ('MultiGrid-Empty-8x8-v0', 8, 3), ('MultiGrid-Empty-16x16-v0', 16, 5),
+                            ('MultiGrid-Empty-5x5-Single-v0', 5, 1)):
   register(_id, dict(layout=(lambda n=_size: layouts.empty_bordered(n, n, goal=(n - 2, n - 2))), n_agents=_agents, view_size=5,
                      max_steps=2 * _size * _size, see_through_walls=True, competitive=False,
                      fixed_spawn=[(1, 1 + _i) for _i in range(_agents)], fixed_mode='always'))

@@ -855,7 +855,12 @@ void mgo_random_actions(const mgo_env* e, uint64_t t, int* actions) {
   uint32_t ctr[4] = {(uint32_t)e->gid, (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)P_ACTION << 28};
   uint32_t key[2] = {(uint32_t)e->seed, (uint32_t)(e->seed >> 32)}, r[4];
   philox4x32_10(ctr, key, r);
-  for (int a = 0; a < e->A; ++a) actions[a] = (int)mulhi32(r[a & 3], 7u);
+  for (int a = 0; a < e->A && a < 4; ++a) actions[a] = (int)mulhi32(r[a], 7u);
+  if (e->A > 4) {                                        /* a second block (counter word + 1) for agents 4.. */
+    ctr[3] |= 1u;
+    philox4x32_10(ctr, key, r);
+    for (int a = 4; a < e->A; ++a) actions[a] = (int)mulhi32(r[a - 4], 7u);
+  }
 }
 
 /* state getters (same packing as include/mgrid.h mg_buffers.env_state): agent word =

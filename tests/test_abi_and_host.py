@@ -78,12 +78,12 @@ def test_registry_mirrors_reference_ids():
 
 def test_registry_specs_are_complete():
   ids = registry.registered_ids()
-  assert len(ids) == 50
+  assert len(ids) == 52
   for i in ids:
     s = registry.spec(i)
     assert {'n_agents', 'view_size', 'max_steps', 'see_through_walls', 'competitive'} <= set(s), i
     assert ('layout' in s) != ('kind' in s), i                      # a fixed layout or a generated kind
-    assert 1 <= s['n_agents'] <= 4, i
+    assert 1 <= s['n_agents'] <= 5, i
     if s.get('minigrid_mode'):                                      # multigrid.py:406-408
       assert s['n_agents'] == 1 and 'Minigrid' in i, i
     if 'layout' in s:

@@ -262,7 +262,7 @@ def test_sharding_invariance(cluttered_cells):
   assert torch.equal(whole.reward[:, 128:], hi.reward) and torch.equal(whole.agent_state[:, :128], lo.agent_state)
 
 
-@pytest.mark.parametrize('A,V', [(1, 5), (2, 5), (4, 5), (3, 7), (3, 3)])
+@pytest.mark.parametrize('A,V', [(1, 5), (2, 5), (4, 5), (5, 5), (3, 7), (3, 3)])
 def test_other_shapes(empty_cells, cluttered_cells, A, V):
   _need_gpu()
   n = 300
@@ -278,6 +278,56 @@ def test_other_shapes(empty_cells, cluttered_cells, A, V):
     orc.step(act)
     _cmp_step(env, orc, 'A%d V%d step %d' % (A, V, t))
   assert env.check_errors() == 0
+
+
+def test_five_agents_replay_and_fast_path(cluttered_cells):
+  """Five agents (the reference's Empty-16x16 / FourRooms-v0 / DoorKey-16x16 ids): the fifth agent's position word rides
+  outside the 64-bit pack and the action / order slots are 8 bytes per env.  Replay with injected order / respawn /
+  reset spawn, then the FAST instantiation (no env_reward output) free-running."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  A, n, seed = 5, 1500, 55
+  env, orc = _make(cluttered_cells, n, seed=seed, n_agents=A, max_steps=40)
+  assert env.actions.shape == (env.stride, 8)
+  rng = np.random.RandomState(seed)
+  orc.reset()
+  _, _, spawn0 = orc.last_draws()
+  env.reset(spawn=torch.from_numpy(spawn0).to(env.device))
+  _cmp(env, orc, 'reset')
+  dev = env.device
+  fifth_first = touches = 0
+  for t in range(130):
+    act = rng.randint(0, 7, size=(A, orc.stride)).astype(np.uint8)
+    act[rng.rand(A, orc.stride) < 0.4] = 2
+    orc.step(act)
+    order, respawn, spawn = orc.last_draws()
+    env.step_replay(torch.from_numpy(act).to(dev), torch.from_numpy(order).to(dev),
+                    torch.from_numpy(respawn).to(dev), torch.from_numpy(spawn).to(dev))
+    _cmp_step(env, orc, 'A5 replay step %d' % t)
+    fifth_first += int((order[0, :n] == 4).sum())
+    touches += int((orc.env_reward[4, :n] > 0).sum())
+  assert env.check_errors() == 0 and orc.errors() == 0
+  assert fifth_first > 0 and touches > 0          # agent 4 acted first somewhere, and reached the goal somewhere
+  # a bad order (agent 4 twice) is reported
+  bad = np.tile(np.array([4, 1, 2, 3, 4], np.uint8)[:, None], (1, orc.stride))
+  env.step_replay(torch.from_numpy(act).to(dev), torch.from_numpy(bad).to(dev), torch.from_numpy(respawn).to(dev),
+                  torch.from_numpy(spawn).to(dev))
+  from multigrid_amd import lib
+  assert env.check_errors() & lib.ERR_BAD_ORDER
+  env.close()
+  fast = BatchedMultiGrid(cluttered_cells, n_envs=n, n_agents=A, seed=seed, max_steps=40)
+  orc = c_oracle.OracleBatch(cluttered_cells, n, A=A, max_steps=40, shaping=1, auto_reset=1, seed=seed)
+  fast.reset()
+  orc.reset()
+  for t in range(90):
+    act = rng.randint(0, 7, size=(A, orc.stride)).astype(np.uint8)
+    act[rng.rand(A, orc.stride) < 0.4] = 2
+    fast.step(torch.from_numpy(act).to(dev))
+    orc.step(act)
+    if t % 8 == 0 or t >= 85:
+      _cmp_step(fast, orc, 'A5 fast step %d' % t)
+  assert fast.check_errors() == 0
+  fast.close()
 
 
 def test_error_reporting(cluttered_cells):
