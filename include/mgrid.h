@@ -164,7 +164,8 @@ typedef struct mg_buffers {
                             because only "> 3" is ever tested, v8:202); word A = step_count | agent done bits<<16
                             | (DOORKEY only) split_idx<<24, the width of the region agents (re)spawn in (doorkey.py:77-78) */
   /* mutable-grid handles only (mutable_grid != 0), NULL / 0 otherwise: */
-  uint32_t* carry;       /* [env_stride]: byte a = kind id of the object agent a carries, 0 = nothing (multigrid.py:490, 926-951) */
+  uint32_t* carry;       /* [env_stride] (five agents: [env_stride][2]): byte a = kind id of the object agent a carries,
+                            0 = nothing (multigrid.py:490, 926-951) */
   uint32_t* grid;        /* bytes [env_stride/64][grid_words*4][64]: kind id of cell ci = y*W + x of env n at byte
                             ((n/64)*grid_words*4 + ci)*64 + n%64 (cells >= W*H are padding).  Cell-major within a 64-env
                             chunk, so a wavefront moves its chunk between HBM and LDS as fully coalesced rows and a lane's

@@ -101,7 +101,7 @@ class BatchedMultiGrid:
     self.carry = self.grid_blocked = None
     if self.mutable_grid:
       self.grid_words = int(b.grid_words)
-      self.carry = _alias(b.carry, (S,), '<i4', dev)[:n]                        # byte a = kind agent a carries
+      self.carry = _alias(b.carry, (S,) if A <= 4 else (S, 2), '<i4', dev)[:n]   # byte a = kind agent a carries
       self.grid_blocked = _alias(b.grid, (S // 64, self.grid_words * 4, 64), '|u1', dev)  # [chunk][cell][lane], include/mgrid.h
     # action buffer in the layout the kernel reads: one dword per env (two with five agents), byte a = agent a's
     # action.  Policies write `env.actions[:N, a]`; `step()` with no argument consumes it.

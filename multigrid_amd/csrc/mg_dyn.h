@@ -179,10 +179,16 @@ __device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, cons
 
 // Inputs of one chunk, requested one chunk ahead with inline-asm loads and retired with a counted
 // s_waitcnt (see load_chunk / wait_chunk in mgrid.hip for why).
+// carried kinds, one byte per agent: a dword up to four agents, two dwords (one u64 in the kernel) for five
+template <int A> struct CarryOf { typedef uint32_t type; };
+template <> struct CarryOf<5> { typedef uint64_t type; };
+template <int A> using carry_t = typename CarryOf<A>::type;
+
 template <int A, int PRE>
 struct DynIn {
-  uint32_t st[4];           // env_state words (A + 1 used)
+  uint32_t st[A + 1 > 4 ? A + 1 : 4];   // env_state words (A + 1 used)
   uint32_t carry, act;
+  uint32_t carry2, act2;    // five agents only: the second dword of the carry word / of the action slots
   uint32_t aux[4];          // MEETUP: goal positions and past distances
   uint32_t pre[PRE];        // this lane's share of the chunk's grid rows (dword lane + 64k), GW <= PRE only
 };
@@ -191,12 +197,17 @@ template <int A, int PRE>
 __device__ __forceinline__ void dyn_load(const Params& p, int64_t env0, int lane, DynIn<A, PRE>& in) {
   const int64_t n = env0 + lane;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) in.st[a] = 0u;
+  for (int a = 0; a < (A + 1 > 4 ? A + 1 : 4); ++a) in.st[a] = 0u;
 #pragma unroll
   for (int a = 0; a <= A; ++a) in.st[a] = asm_load_u32(p.env_state + n * (A + 1) + a);
-  in.carry = asm_load_u32(p.carry + n);
-  in.act = 0x06060606u;
-  if (p.op == OP_STEP && !p.random_actions) in.act = asm_load_u32(p.actions + n);
+  in.carry = asm_load_u32(p.carry + n * kSlotWords<A>);
+  in.act = in.act2 = 0x06060606u;
+  in.carry2 = 0u;
+  if (A > 4) in.carry2 = asm_load_u32(p.carry + n * kSlotWords<A> + 1);
+  if (p.op == OP_STEP && !p.random_actions) {
+    in.act = asm_load_u32(p.actions + n * kSlotWords<A>);
+    if (A > 4) in.act2 = asm_load_u32(p.actions + n * kSlotWords<A> + 1);
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     in.aux[k] = 0u;
@@ -212,12 +223,21 @@ __device__ __forceinline__ void dyn_load(const Params& p, int64_t env0, int lane
 
 template <int A, int K, int PRE>
 __device__ __forceinline__ void dyn_wait(DynIn<A, PRE>& in) {
-  static_assert(A <= 3 && PRE % 16 == 0, "operand lists below");
-  asm volatile("s_waitcnt vmcnt(%10)"
-               : "+v"(in.st[0]), "+v"(in.st[1]), "+v"(in.st[2]), "+v"(in.st[3]),
-                 "+v"(in.carry), "+v"(in.act), "+v"(in.aux[0]), "+v"(in.aux[1]), "+v"(in.aux[2]), "+v"(in.aux[3])
-               : "n"(K)
-               : "memory");
+  static_assert((A <= 3 || A == 5) && PRE % 16 == 0, "operand lists below");
+  if constexpr (A <= 3) {
+    asm volatile("s_waitcnt vmcnt(%10)"
+                 : "+v"(in.st[0]), "+v"(in.st[1]), "+v"(in.st[2]), "+v"(in.st[3]),
+                   "+v"(in.carry), "+v"(in.act), "+v"(in.aux[0]), "+v"(in.aux[1]), "+v"(in.aux[2]), "+v"(in.aux[3])
+                 : "n"(K)
+                 : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(%14)"
+                 : "+v"(in.st[0]), "+v"(in.st[1]), "+v"(in.st[2]), "+v"(in.st[3]), "+v"(in.st[4]), "+v"(in.st[5]),
+                   "+v"(in.carry), "+v"(in.carry2), "+v"(in.act), "+v"(in.act2),
+                   "+v"(in.aux[0]), "+v"(in.aux[1]), "+v"(in.aux[2]), "+v"(in.aux[3])
+                 : "n"(K)
+                 : "memory");
+  }
   // the grid rows: volatile asm statements keep their order, so no use of these registers can move above the wait
 #pragma unroll
   for (int k = 0; k < PRE; k += 16)
@@ -370,7 +390,8 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     shw[a] = w & ~AW_POSDIR;
   }
   uint32_t st = in.st[A];
-  uint32_t carry = in.carry;
+  carry_t<A> carry = in.carry;
+  if constexpr (A > 4) carry |= (uint64_t)in.carry2 << 32;
   uint32_t goal[3] = {in.aux[0], in.aux[1], in.aux[2]};       // MEETUP: goal_pos[2k] | goal_pos[2k+1] << 16, each x | y<<6
   uint32_t past = in.aux[3];                                  // MEETUP: past_goal_dist, one byte per agent
   // agents (re)spawn at x < spawn_w: the DoorKey split (doorkey.py:77-78), the whole grid otherwise
@@ -382,7 +403,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     if (p.random_actions) actw = draw_actions<A>(p, n, gid, active);
     else {
 #pragma unroll
-      for (int a = 0; a < A; ++a) actw |= min((in.act >> (8 * a)) & 255u, 7u) << (3 * a);
+      for (int a = 0; a < A; ++a) actw |= min(((a < 4 ? in.act >> (8 * a) : in.act2 >> (8 * (a - 4)))) & 255u, 7u) << (3 * a);
     }
     uint32_t step = (st & 0xFFFFu) + 1u;                                        // multigrid.py:968
     uint32_t dbits = (st >> 16) & all;
@@ -407,7 +428,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       const int ci = g_off(p, fx, fy);
       const uint32_t kf = g_get(g, ci);
       const uint32_t fl = lut[kf];
-      const uint32_t ck = (carry >> (8 * a)) & 255u;
+      const uint32_t ck = (uint32_t)(carry >> (8 * a)) & 255u;
       const int nd = (act == 0u) ? ((d + 3) & 3) : (act == 1u) ? ((d + 1) & 3) : d;   // :867-876
       uint32_t npd = (s & AW_POS) | ((uint32_t)nd << 12);
       if (act == 2u) {                                                          // _forward :906-924
@@ -421,7 +442,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
               const bool inj = p.objdrop != nullptr;
               const uint32_t w = place_dyn<A>(p, g, pd, all, a, P_OBJDROP, p.W, inj, inj ? p.objdrop[n * A + a] : 0u, false, gid);
               gs(g_off(p, aw_x(w), aw_y(w)), ck);
-              carry &= ~(255u << (8 * a));
+              carry &= ~((carry_t<A>)255u << (8 * a));
               err |= w >> 16;
             }
             const bool inj = p.respawn != nullptr;
@@ -436,13 +457,13 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
         }
       } else if (act == 3u) {                                                   // _pickup :926-938
         if ((fl & F_PICKUP) && ck == 0u) {
-          carry |= kf << (8 * a);
+          carry |= (carry_t<A>)kf << (8 * a);
           gs(ci, 0u);
         }
       } else if (act == 4u) {                                                   // _drop :940-951
         if ((fl & F_FREE) && !blocked && ck != 0u) {
           gs(ci, ck);
-          carry &= ~(255u << (8 * a));
+          carry &= ~((carry_t<A>)255u << (8 * a));
         }
       } else if (act == 5u) {                                                   // _toggle :953-961
         if (fl & F_DOOR) {                                                      // Door.toggle :112-122
@@ -503,7 +524,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   const bool do_reset = (!is_step) ? (p.mask ? (p.mask[active ? n : 0] != 0) : true) : (done_flag && p.auto_reset);
   if (do_reset) {
     for (int ci = 0; ci < cells; ++ci) gs((int)pidx[ci] * kCellB, (base[ci >> 2] >> (8 * (ci & 3))) & 255u);
-    carry = 0u;                                                                 // multigrid.py:490
+    carry = 0;                                                                  // multigrid.py:490
     int door = 1;
     const bool inj_gen = p.reset_gen != nullptr;
     const uint32_t genw = inj_gen ? p.reset_gen[n] : 0u;
@@ -605,7 +626,8 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 #pragma unroll
     for (int a = 0; a < A; ++a) p.env_state[n * (A + 1) + a] = shw[a] | pd_get(pd, a);
     p.env_state[n * (A + 1) + A] = st;
-    p.carry[n] = carry;
+    p.carry[n * kSlotWords<A>] = (uint32_t)carry;
+    if constexpr (A > 4) p.carry[n * kSlotWords<A> + 1] = (uint32_t)(carry >> 32);
     if (p.aux) reinterpret_cast<uint4*>(p.aux)[n] = make_uint4(goal[0], goal[1], goal[2], past);
     uint64_t dd = (uint64_t)done_flag << (8 * A);
 #pragma unroll
@@ -635,7 +657,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     for (int a = 0; a < A; ++a) {
       uint32_t s[NW + 1];
       uint64_t vm;
-      dyn_view<V>(p, g, lut, pd_get(pd, a), (carry >> (8 * a)) & 255u, s, vm);
+      dyn_view<V>(p, g, lut, pd_get(pd, a), (uint32_t)(carry >> (8 * a)) & 255u, s, vm);
       emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB);
     }
   }

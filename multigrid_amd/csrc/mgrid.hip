@@ -828,7 +828,7 @@ const Variant kVariants[] = {
 struct DynVariant { int A, V; bool full; int pre; kernel_fn fn; };
 #define MG_DYN(A, V, FULL, PRE) {A, FULL ? 0 : V, FULL, PRE, mg_dyn_kernel<A, V, FULL, PRE>}
 const DynVariant kDynVariants[] = {
-    MG_DYN(1, 7, false, 16), MG_DYN(2, 7, false, 16), MG_DYN(3, 7, false, 16),
+    MG_DYN(1, 7, false, 16), MG_DYN(2, 7, false, 16), MG_DYN(3, 7, false, 16), MG_DYN(5, 7, false, 16),
     MG_DYN(1, 5, false, 16), MG_DYN(2, 5, false, 16), MG_DYN(3, 5, false, 16),
     MG_DYN(1, 5, false, 64), MG_DYN(2, 5, false, 64), MG_DYN(3, 5, false, 64),
     // fully observed kinds (no views; the V parameter is unused)
@@ -1069,7 +1069,7 @@ int enable_dynamic(mg_handle* h, const std::vector<uint8_t>& kinds, int gx, int 
   int rc = MG_OK;
   if (!h->grid) {
     if (rc == MG_OK) rc = dalloc(h, &h->base_grid, (size_t)h->GW);
-    if (rc == MG_OK) rc = dalloc(h, &h->carry, (size_t)h->stride);
+    if (rc == MG_OK) rc = dalloc(h, &h->carry, (size_t)h->stride * (h->cfg.n_agents > 4 ? 2 : 1));
     if (rc == MG_OK) rc = dalloc(h, &h->grid, (size_t)h->n_chunks * h->GW * kWave);
     if (rc != MG_OK) return rc;
   }
@@ -1139,6 +1139,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
       if (c.gen_n_clutter < 0 || c.gen_n_goals < 0 || c.gen_n_goals + c.gen_n_clutter > MG_MAX_SCATTER)
         return fail(MG_EINVAL, "gen_n_goals + gen_n_clutter must be in [0, 64]");
       if (c.env_kind == MG_KIND_CLUTTERED && c.gen_n_goals > 1) return fail(MG_EINVAL, "Cluttered has one goal: gen_n_goals is 0 or 1");
+      if (c.env_kind == MG_KIND_MEETUP && c.n_agents > 4) return fail(MG_EUNSUPPORTED, "Meetup supports up to four agents");
       if (c.env_kind == MG_KIND_MEETUP && (c.gen_n_goals < 1 || c.gen_n_goals > kMaxGoals))
         return fail(MG_EUNSUPPORTED, "Meetup supports 1 to 6 goals");
       if (c.gen_n_goals + c.gen_n_clutter + 1 + c.n_agents > interior) return fail(MG_EINVAL, "more objects than interior cells");

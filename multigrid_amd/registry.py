@@ -53,9 +53,8 @@ for _id, _size, _agents in (('MultiGrid-Empty-5x5-v0', 5, 2), ('MultiGrid-Empty-
                      fixed_spawn=[(1, 1 + _i) for _i in range(_agents)], fixed_mode='always'))
 
 # DoorKeyEnv family (multigrid_envs/doorkey.py:27-161): view 7 (multigrid.py:333 default),
-# max_steps 10*size^2, layouts drawn per env and per reset on device.  The 16x16 five-agent id is
-# not registered: the kernels pack at most four agents.
-for _id, _size, _agents in (('MultiGrid-DoorKey-6x6-v0', 6, 2), ('MultiGrid-DoorKey-8x8-v0', 8, 3),
+# max_steps 10*size^2, layouts drawn per env and per reset on device.
+for _id, _size, _agents in (('MultiGrid-DoorKey-6x6-v0', 6, 2), ('MultiGrid-DoorKey-8x8-v0', 8, 3), ('MultiGrid-DoorKey-16x16-v0', 16, 5),
                             ('MultiGrid-DoorKey-5x5-Single-v0', 5, 1), ('MultiGrid-DoorKey-6x6-Single-v0', 6, 1),
                             ('MultiGrid-DoorKey-8x8-Single-v0', 8, 1), ('MultiGrid-DoorKey-16x16-Single-v0', 16, 1)):
   register(_id, dict(kind='doorkey', size=_size, n_agents=_agents, view_size=7, max_steps=10 * _size * _size,
@@ -88,8 +87,9 @@ for _id, _size, _two in (('MultiGrid-FourRooms-Minigrid-v0', 15, False), ('Multi
   register(_id, dict(kind='fourrooms', size=_size, n_agents=1, view_size=5, max_steps=100, see_through_walls=False,
                      competitive=False, two_rooms=_two, minigrid_mode=True))
 
-# FourRoomsEnv (multigrid_envs/fourrooms.py:25-134): max_steps 100, gaps / agents / goal drawn per reset.  The default
-# 19x19 id has five agents (not instantiated).
+# FourRoomsEnv (multigrid_envs/fourrooms.py:25-134): max_steps 100, gaps / agents / goal drawn per reset.
+register('MultiGrid-FourRooms-v0', dict(kind='fourrooms', size=19, n_agents=5, view_size=7, max_steps=100,
+                                        see_through_walls=False, competitive=False))
 register('MultiGrid-FourRooms-15x15-v0', dict(kind='fourrooms', size=15, n_agents=3, view_size=5, max_steps=100,
                                               see_through_walls=False, competitive=False))
 register('MultiGrid-FourRooms-Single-v0', dict(kind='fourrooms', size=19, n_agents=1, view_size=7, max_steps=100,

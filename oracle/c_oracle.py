@@ -355,8 +355,8 @@ class OracleBatch:
     self.t += 1
 
   def dyn_state(self):
-    """(carry uint32[stride], kinds uint8[stride, H, W]) of the mutable-grid state."""
-    carry = np.zeros(self.stride, np.uint32)
+    """(carry uint32[stride] — [stride, 2] with five agents —, kinds uint8[stride, H, W]) of the mutable-grid state."""
+    carry = np.zeros(self.stride if self.A <= 4 else (self.stride, 2), np.uint32)
     kinds = np.zeros((self.stride, self.H, self.W), np.uint8)
     self.L.mgo_batch_dyn_state(self.envs, self.n, self.stride, carry.ctypes.data_as(C.c_void_p), _p(kinds, u8p))
     return carry, kinds

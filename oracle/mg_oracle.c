@@ -1069,12 +1069,17 @@ void mgo_batch_step_ex(mgo_env** envs, int64_t n, int64_t stride, const uint8_t*
   }
 }
 
-void mgo_batch_dyn_state(mgo_env** envs, int64_t n, int64_t stride, uint32_t* carry /* [stride] */,
+/* carry: [stride] words, or [stride][2] with five agents (byte a of the pair = what agent a carries) */
+void mgo_batch_dyn_state(mgo_env** envs, int64_t n, int64_t stride, uint32_t* carry,
                          uint8_t* kinds /* [stride][H*W] */) {
   (void)stride;
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
-    carry[i] = mgo_carry_word(envs[i]);
+    if (envs[i]->A > 4) {
+      carry[2 * i] = mgo_carry_word(envs[i]);
+      carry[2 * i + 1] = 0;
+      for (int a = 4; a < envs[i]->A; ++a) carry[2 * i + 1] |= (uint32_t)kind_of(envs[i]->carrying[a]) << (8 * (a - 4));
+    } else carry[i] = mgo_carry_word(envs[i]);
     mgo_grid_kinds(envs[i], kinds + i * envs[i]->W * envs[i]->H);
   }
 }

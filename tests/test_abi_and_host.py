@@ -78,7 +78,7 @@ def test_registry_mirrors_reference_ids():
 
 def test_registry_specs_are_complete():
   ids = registry.registered_ids()
-  assert len(ids) == 52
+  assert len(ids) == 54
   for i in ids:
     s = registry.spec(i)
     assert {'n_agents', 'view_size', 'max_steps', 'see_through_walls', 'competitive'} <= set(s), i
