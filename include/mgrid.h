@@ -86,6 +86,8 @@ extern "C" {
                                  env and per reset; the goal is placed after the agents.  Injected as three scatter pairs:
                                  (gap_top_y, gap_left_x), (gap_right_x, gap_bottom_y), (goal_x, goal_y). */
 #define MG_GEN_LAVA 1      /* gen_flags: Cluttered walls_are_lava */
+#define MG_GEN_LAVAWALL 4  /* gen_flags: Cluttered obstacles are LavaWall objects (lava_walls.py:25-38, 79-80): deadly like lava,
+                              transparent, but encoded as grey walls.  In a cell triple / kind id: lava with colour grey. */
 #define MG_GEN_TWO_ROOMS 2 /* gen_flags: FourRooms two_rooms=True (fourrooms.py:75-83): only the vertical wall is built; its lower
                               gap is not drawn on grids with height < 7 */
 #define MG_MAX_SCATTER 64  /* gen_n_goals + gen_n_clutter */

@@ -59,7 +59,8 @@ class BatchedMultiGrid:
         see_through_walls=int(see_through_walls), competitive=int(competitive),
         shaping_kind={None: 0, 'none': 0, 'v8': 1, 'v7': 2}[shaping], auto_reset=int(auto_reset),
         env_kind=_lib.KINDS[kind], emit_env_reward=int(emit_env_reward),
-        gen_n_goals=int(n_goals), gen_n_clutter=int(n_clutter), gen_flags=(_lib.GEN_LAVA if walls_are_lava else 0) | (_lib.GEN_TWO_ROOMS if two_rooms else 0),
+        gen_n_goals=int(n_goals), gen_n_clutter=int(n_clutter), gen_flags=(_lib.GEN_LAVAWALL if walls_are_lava == 'lavawall' else _lib.GEN_LAVA if walls_are_lava else 0)
+        | (_lib.GEN_TWO_ROOMS if two_rooms else 0),
         kernel_path={'auto': 0, 'generic': 1, 'table': 2}[kernel_path],
         n_envs=n_envs, env_id_base=env_id_base, seed=seed)
     self.h = C.c_void_p()

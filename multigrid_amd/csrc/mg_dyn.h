@@ -29,6 +29,7 @@ constexpr uint32_t K_DOOR_YELLOW_LOCKED = 128 + 4 * 4 + 2;     // Door('yellow',
 constexpr uint32_t K_KEY_YELLOW = MG_T_KEY * 8 + 4;            // Key('yellow'), doorkey.py:65
 constexpr uint32_t K_DOOR_RED_LOCKED = 128 + 0 * 4 + 2;        // Door(color='red', is_locked=True), meetup.py:69
 constexpr uint32_t K_LAVA = MG_T_LAVA * 8 + 0;                 // red lava
+constexpr uint32_t K_LAVAWALL = MG_T_LAVA * 8 + 5;             // LavaWall (lava_walls.py:25-38)
 constexpr uint32_t K_AGENT0 = 224;                             // 224 + 4*agent + dir: LDS only, never stored to HBM
 enum { P_GEN = 4, P_KEY = 5, P_OBJDROP = 6 };
 
@@ -54,7 +55,10 @@ __host__ __device__ inline uint32_t kind_word(uint32_t k) {
     case MG_T_KEY: case MG_T_BALL: w |= F_PICKUP; break;
     case MG_T_BOX: w |= F_PICKUP | F_BOX; break;
     case MG_T_GOAL: w |= F_KILL | F_GOAL; break;
-    case MG_T_LAVA: w |= F_KILL; break;
+    case MG_T_LAVA:            // grey lava = LavaWall (lava_walls.py:25-38): deadly and transparent, encoded as a grey wall
+      if (color == 5u) w = (uint32_t)MG_T_WALL | (5u << 8);
+      w |= F_KILL;
+      break;
     default: break;                                            // a solid, inert object
   }
   return w;
@@ -545,7 +549,8 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       // place_obj for every scattered object in draw order (cluttered.py:28-36, meetup.py:67-72): the
       // goal / goal doors first, then the clutter.  No agent has a position yet (multigrid.py:471-473).
       const uint32_t k1 = p.kind == MG_KIND_MEETUP ? K_DOOR_RED_LOCKED : K_GOAL;
-      const uint32_t k2 = (p.kind == MG_KIND_CLUTTERED && (p.gen_flags & MG_GEN_LAVA)) ? K_LAVA : K_WALL;
+      const uint32_t k2 = p.kind != MG_KIND_CLUTTERED ? K_WALL
+                          : (p.gen_flags & MG_GEN_LAVAWALL) ? K_LAVAWALL : (p.gen_flags & MG_GEN_LAVA) ? K_LAVA : K_WALL;
       const int n_obj = p.n_goals + p.n_clutter;
       const bool inj = p.scatter != nullptr;
       goal[0] = goal[1] = goal[2] = 0xFFFFFFFFu;

@@ -1292,7 +1292,10 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
         case MG_T_UNSEEN: case MG_T_EMPTY: w = (uint32_t)MG_T_EMPTY | F_FREE; cidx[(size_t)y * W + x] = (uint16_t)n_free++; break;
         case MG_T_WALL: w |= F_OPAQUE; break;
         case MG_T_GOAL: w |= F_KILL | F_GOAL; break;
-        case MG_T_LAVA: w |= F_KILL; break;
+        case MG_T_LAVA:          // grey lava = LavaWall (lava_walls.py:25-38): it kills, it is transparent, it looks like a grey wall
+          if (c[1] == 5) w = (uint32_t)MG_T_WALL | (5u << 8);
+          w |= F_KILL;
+          break;
         default:
           return fail(MG_EUNSUPPORTED, "static maps hold only empty/wall/goal/lava cells");
       }

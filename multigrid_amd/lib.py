@@ -14,6 +14,7 @@ KINDS = {'static': KIND_STATIC, 'doorkey': KIND_DOORKEY, 'cluttered': KIND_CLUTT
          'fourrooms': KIND_FOURROOMS}
 GEN_LAVA = 1
 GEN_TWO_ROOMS = 2
+GEN_LAVAWALL = 4
 FIXED_OFF, FIXED_ALWAYS, FIXED_AT_RESET = 0, 1, 2
 
 

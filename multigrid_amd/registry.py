@@ -79,6 +79,9 @@ for _id, _size, _clutter, _lava in (('MultiGrid-Cluttered40-Minigrid-v0', 15, 40
                                     ('MultiGrid-MediumCluttered15-Minigrid-v0', 10, 15, False)):
   register(_id, dict(kind='cluttered', size=_size, n_agents=1, view_size=5, max_steps=250, n_goals=1, n_clutter=_clutter,
                      walls_are_lava=_lava, see_through_walls=False, competitive=False, minigrid_mode=True))
+# WallsAreLavaMultiGrid (lava_walls.py:57-88): Cluttered's generator with LavaWall obstacles, one agent, competitive
+register('MultiGrid-WallsAreLava-v0', dict(kind='cluttered', size=15, n_agents=1, view_size=5, max_steps=250, n_goals=1, n_clutter=25,
+                                           walls_are_lava='lavawall', see_through_walls=False, competitive=True, minigrid_mode=True))
 for _id, _size in (('MultiGrid-Empty-Random-6x6-Minigrid-v0', 6), ('MultiGrid-Empty-Random-15x15-Minigrid-v0', 15)):
   register(_id, dict(kind='cluttered', size=_size, n_agents=1, view_size=5, max_steps=2 * _size * _size, n_goals=1, n_clutter=0,
                      see_through_walls=True, competitive=False, minigrid_mode=True))

@@ -109,7 +109,7 @@ def _configure(L, h, kind, n_goals, n_clutter, lava, fixed_spawn=None, fixed_mod
   if two_rooms:
     L.mgo_set_two_rooms(h, 1)
   if kind in ('cluttered', 'meetup'):
-    if not L.mgo_set_scatter(h, n_goals, n_clutter, int(lava)):
+    if not L.mgo_set_scatter(h, n_goals, n_clutter, 2 if lava == 'lavawall' else int(bool(lava))):
       raise ValueError('bad scatter generator parameters')
 
 

@@ -47,6 +47,8 @@ static const obj_t NONE = {T_NONE, 0, 0, 0};
 
 /* gym_minigrid.minigrid.DIR_TO_VEC (consistent with get_view_exts,
  * multigrid.py:754-769) */
+/* WorldObj.encode()[0]; LavaWall (lava_walls.py:25-38) is a grey 'lava' object whose encoding is a grey wall's */
+#define enc_type(o) (((o).type == T_LAVA && (o).color == C_GREY) ? T_WALL : (o).type)
 static const int DIR_TO_VEC[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
 
 typedef struct { obj_t c[MAXW * MAXW]; int w, h; } grid_t;
@@ -401,7 +403,7 @@ static void gen_agent_obs(const mgo_env* e, int a, uint8_t* image, uint8_t* dire
       if (!mask[i * V + j]) { p[0] = p[1] = p[2] = 0; continue; }   /* unseen */
       obj_t v = view_get(cur, i, j);
       if (v.type == T_NONE) { p[0] = T_EMPTY; p[1] = 0; p[2] = 0; }
-      else { p[0] = v.type; p[1] = v.color; p[2] = v.state; }
+      else { p[0] = enc_type(v); p[1] = v.color; p[2] = v.state; }
     }
   *direction = (uint8_t)e->adir[a];                               /* multigrid.py:1083 */
 }
@@ -477,7 +479,8 @@ static void gen_scatter(mgo_env* e) {
   if (e->kind == KIND_CLUTTERED) {
     if (e->n_goals) place_scatter(e, goal, idx++, NULL, NULL);    /* cluttered.py:28-29 */
     else grid_set(&e->grid, W - 2, H - 2, goal);                  /* cluttered.py:31 */
-    for (int c = 0; c < e->n_clutter; ++c) place_scatter(e, e->lava ? lava : wall, idx++, NULL, NULL);   /* :32-36 */
+    const obj_t lavawall = {T_LAVA, C_GREY, 0, 0};                /* lava_walls.py:79-80 */
+    for (int c = 0; c < e->n_clutter; ++c) place_scatter(e, e->lava == 2 ? lavawall : e->lava ? lava : wall, idx++, NULL, NULL);   /* :32-36 */
   } else {
     for (int i = 0; i < e->n_goals; ++i) place_scatter(e, door, idx++, &e->goal_x[i], &e->goal_y[i]);    /* meetup.py:67-70 */
     for (int c = 0; c < e->n_clutter; ++c) place_scatter(e, wall, idx++, NULL, NULL);                   /* :71-72 */
@@ -574,7 +577,7 @@ void mgo_get_obs(const mgo_env* e, uint8_t* image, uint8_t* dir /* [A] */) {
         for (int j = 0; j < e->H; ++j) {
           obj_t v = grid_get(&e->grid, i, j);
           uint8_t* p = image + a * cb + (i * e->H + j) * 3;
-          if (v.type == T_NONE) { p[0] = T_EMPTY; p[1] = 0; p[2] = 0; } else { p[0] = v.type; p[1] = v.color; p[2] = v.state; }
+          if (v.type == T_NONE) { p[0] = T_EMPTY; p[1] = 0; p[2] = 0; } else { p[0] = enc_type(v); p[1] = v.color; p[2] = v.state; }
         }
       dir[a] = (uint8_t)e->adir[a];
     }
@@ -941,7 +944,7 @@ void mgo_get_grid(const mgo_env* e, uint8_t* cells /* [W*H*3], None -> (1,0,0) *
     for (int x = 0; x < e->W; ++x) {
       obj_t o = grid_get(&e->grid, x, y);
       uint8_t* p = cells + (y * e->W + x) * 3;
-      if (o.type == T_NONE) { p[0] = T_EMPTY; p[1] = p[2] = 0; } else { p[0] = o.type; p[1] = o.color; p[2] = o.state; }
+      if (o.type == T_NONE) { p[0] = T_EMPTY; p[1] = p[2] = 0; } else { p[0] = enc_type(o); p[1] = o.color; p[2] = o.state; }
     }
 }
 /* test hook: put an object on the live grid (used by DoorKey-style known-answer tests) */

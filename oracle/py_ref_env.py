@@ -71,6 +71,18 @@ class Lava(Thing):
     super().__init__('lava', 'red')
 
 
+class LavaWall(Thing):
+  """lava_walls.py:25-38: deadly like Lava (type 'lava', can_overlap), transparent (WorldObj.see_behind), but its encoding is
+  a grey wall's."""
+  overlap = True
+
+  def __init__(self):
+    super().__init__('lava', 'grey')
+
+  def encode(self):
+    return (OBJ_IDX['wall'], COLOR_IDX['grey'], 0)
+
+
 class Floor(Thing):
   overlap = True
 
@@ -154,7 +166,7 @@ def decode_cell(t, c, s):
   if kind == 'goal':
     return Goal()
   if kind == 'lava':
-    return Lava()
+    return LavaWall() if IDX_COLOR[int(c)] == 'grey' else Lava()
   if kind == 'floor':
     return Floor(IDX_COLOR[int(c)])
   if kind == 'key':
@@ -573,7 +585,7 @@ class PyClutteredEnv(PyRefEnv):
     else:
       self.grid.set(self.size - 2, self.size - 2, Goal())               # :30-31
     for _ in range(self.n_clutter):                                      # :32-36
-      self.place_obj(Lava() if self.walls_are_lava else Wall())
+      self.place_obj(LavaWall() if self.walls_are_lava == 'lavawall' else Lava() if self.walls_are_lava else Wall())
     for a in range(self.n_agents):                                       # :38
       self.place_one_agent(a)
 

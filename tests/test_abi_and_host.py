@@ -78,14 +78,14 @@ def test_registry_mirrors_reference_ids():
 
 def test_registry_specs_are_complete():
   ids = registry.registered_ids()
-  assert len(ids) == 54
+  assert len(ids) == 55
   for i in ids:
     s = registry.spec(i)
     assert {'n_agents', 'view_size', 'max_steps', 'see_through_walls', 'competitive'} <= set(s), i
     assert ('layout' in s) != ('kind' in s), i                      # a fixed layout or a generated kind
     assert 1 <= s['n_agents'] <= 5, i
     if s.get('minigrid_mode'):                                      # multigrid.py:406-408
-      assert s['n_agents'] == 1 and 'Minigrid' in i, i
+      assert s['n_agents'] == 1 and ('Minigrid' in i or 'WallsAreLava' in i), i
     if 'layout' in s:
       cells = s['layout']()
       assert cells.shape[2] == 3 and (cells[..., 0] == 8).sum() == 1, i

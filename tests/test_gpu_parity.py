@@ -330,6 +330,33 @@ def test_five_agents_replay_and_fast_path(cluttered_cells):
   fast.close()
 
 
+def test_lavawall_cells_on_a_static_map(empty_cells):
+  """A caller-supplied layout with LavaWall cells (lava, colour grey: lava_walls.py:25-38) on the shared-map kernels"""
+  _need_gpu()
+  cells = empty_cells.copy()
+  for x, y in [(4, 4), (9, 3), (6, 10), (11, 11), (7, 7), (3, 12)]:
+    cells[y, x] = (9, 5, 0)
+  cells[5, 5] = (9, 0, 0)
+  n = 1500
+  env, orc = _make(cells, n, seed=61, max_steps=60)
+  assert not env.mutable_grid
+  rng = np.random.RandomState(61)
+  env.reset()
+  orc.reset()
+  _cmp(env, orc, 'reset')
+  seen_as_wall = 0
+  for t in range(150):
+    act = rng.randint(0, 7, size=(3, orc.stride)).astype(np.uint8)
+    act[rng.rand(3, orc.stride) < 0.4] = 2
+    env.step(torch.from_numpy(act).to(env.device))
+    orc.step(act)
+    _cmp_step(env, orc, 'lavawall step %d' % t)
+  img = env.obs_image.cpu().numpy()
+  assert (img[..., 0] == 9).any() and not ((img[..., 0] == 9) & (img[..., 1] == 5)).any()   # red lava shows, LavaWall never does
+  assert env.check_errors() == 0 and orc.errors() == 0
+  env.close()
+
+
 def test_error_reporting(cluttered_cells):
   _need_gpu()
   from multigrid_amd import lib

@@ -192,3 +192,18 @@ def test_lava_kills_without_reward(make, empty_cells):
   e.step([2, 6, 6], respawn=[(8, 8, 3), (-1, -1, 0), (-1, -1, 0)])
   assert e.env_rewards == [0, 0, 0]
   assert e.agent_pos[0] == (8, 8) and e.cell(6, 5) == (9, 0, 0)
+
+
+def test_lavawall_looks_like_a_wall_kills_like_lava_and_is_transparent(make, empty_cells):
+  """lava_walls.py:25-38: type 'lava' (multigrid.py:915-916 ends the agent), WorldObj.see_behind() is True, encode() is a grey wall's"""
+  e = make(empty_cells, [(5, 5, 0)] + FAR)
+  e.put_obj(7, 5, 9, 5)                 # LavaWall two cells ahead
+  e.put_obj(8, 5, 9, 0)                 # red lava behind it
+  obs = e.obs()['image'][0]
+  assert tuple(obs[2, 2]) == WALL       # (vx, vy) = (2, 4 - 2): looks like a grey wall ...
+  assert tuple(obs[2, 1]) == (9, 0, 0)  # ... but the cell behind it is visible
+  e.step([2, 6, 6])
+  assert e.agent_pos[0] == (6, 5)
+  _, rew, done, _ = e.step([2, 6, 6], respawn=[(3, 3, 1), (-1, -1, 0), (-1, -1, 0)])
+  assert e.agent_pos[0] == (3, 3) and e.env_rewards[0] == 0        # finished on the LavaWall, no reward, respawned
+  assert e.cell(7, 5) != EMPTY          # the object itself is still there

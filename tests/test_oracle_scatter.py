@@ -233,6 +233,12 @@ def test_cluttered_lava_small_cross():
   assert ev['episodes'] > 40 and ev['deaths'] > 20 and ev['reward'] > 0, ev
 
 
+def test_walls_are_lava_cross():
+  """WallsAreLavaMultiGrid's obstacles (lava_walls.py:25-38, 79-80): the C restatement against the Python one"""
+  ev = _cross('cluttered', 7, 1, 3000, seed=9, max_steps=50, n_clutter=6, randomize_goal=True, walls_are_lava='lavawall')
+  assert ev['episodes'] > 40 and ev['deaths'] > 20 and ev['reward'] > 0, ev
+
+
 def test_scatter_generator_statistics():
   """Every scattered object lands on a distinct interior cell; goal position is uniform-ish over the interior."""
   seen = set()
