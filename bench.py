@@ -126,11 +126,11 @@ def main():
   # bytes one env-step has to move: obs + dir/done + f64 rewards + actions + env_state r/w,
   # and for per-env grids: carry r/w + grid rows r/w (+ aux r/w)
   b_alg = B_ALG_PER_ENV_STEP if headline else (
-      (env.width * env.height * 3 if env.obs_full is not None else A * V * V * 3) + (4 if A < 4 else 8) + 8 * A + 4 +
-      8 * (A + 1) + ((8 + 8 * env.grid_words) if env.mutable_grid else 0) + (32 if env.aux is not None else 0))
+      (env.width * env.height * 3 if env.obs_full is not None else A * V * V * 3) + (4 if A < 4 else 8) + 8 * A + env.slots +
+      8 * (A + 1) + ((2 * env.slots + 8 * env.grid_words) if env.mutable_grid else 0) + (32 if env.aux is not None else 0))
   gen = torch.Generator(device=dev)
   gen.manual_seed(1234 + rank)
-  ring = torch.randint(0, 7, (ACTION_RING, env.stride, 4), dtype=torch.uint8, device=dev, generator=gen)
+  ring = torch.randint(0, 7, (ACTION_RING, env.stride, env.slots), dtype=torch.uint8, device=dev, generator=gen)
   env.reset()
 
   def run(k):
@@ -172,7 +172,8 @@ def main():
                    'envs_per_gpu': n, 'global_envs': n * world, 'parallelism': 'env-sharded x%d, no collective in step' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(n) if headline else None,
-                     'kernel': 'mg_kernel<3,5,%s,fast>' % env.launch_info()['path'] if headline else 'mg_dyn_kernel<%d,%d>' % (A, V),
+                     'kernel': ('mg_dyn_kernel<%d,%d>' % (A, V)) if env.mutable_grid else
+                               ('mg_kernel<%d,%d,%s,fast>' % (A, V, env.launch_info()['path'])),
                      'kernel_ms': kernel_ms, 'launch': env.launch_info(), 'alg_bytes_per_launch': b_alg * n},
         'device_errors': errs,
     }
