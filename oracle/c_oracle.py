@@ -70,6 +70,8 @@ def lib():
     L.mgo_step_ex.argtypes = [C.c_void_p, i32p, u8p, i8p, i8p, i8p, i8p, C.c_uint64, u8p, u8p, f64p, f64p, u8p]
     L.mgo_carry_word.restype = C.c_uint32
     L.mgo_carry_word.argtypes = [C.c_void_p]
+    L.mgo_carry_word64.restype = C.c_uint64
+    L.mgo_carry_word64.argtypes = [C.c_void_p]
     L.mgo_grid_kinds.argtypes = [C.c_void_p, u8p]
     L.mgo_last_gen.argtypes = [C.c_void_p, i8p, i8p]
     L.mgo_batch_reset_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, u8p, i8p, i8p, C.c_uint64, u8p, u8p]
@@ -268,7 +270,7 @@ class OracleEnv:
     self.L.mgo_set_step_count(self.h, s)
 
   def carry_word(self):
-    return self.L.mgo_carry_word(self.h)
+    return int(self.L.mgo_carry_word64(self.h))
 
   def grid_kinds(self):
     g = np.zeros((self.H, self.W), np.uint8)

@@ -895,6 +895,12 @@ static uint8_t kind_of(obj_t o) {
   if (o.type == T_DOOR) return (uint8_t)(128 + o.color * 4 + o.state);
   return (uint8_t)(o.type * 8 + o.color);
 }
+/* all agents, byte a = kind carried by agent a (five agents need more than one word) */
+uint64_t mgo_carry_word64(const mgo_env* e) {
+  uint64_t w = 0;
+  for (int a = 0; a < e->A && a < 8; ++a) w |= (uint64_t)kind_of(e->carrying[a]) << (8 * a);
+  return w;
+}
 uint32_t mgo_carry_word(const mgo_env* e) {
   uint32_t w = 0;
   for (int a = 0; a < e->A && a < 4; ++a) w |= (uint32_t)kind_of(e->carrying[a]) << (8 * a);

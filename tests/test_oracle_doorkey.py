@@ -264,6 +264,12 @@ def test_doorkey_cross_8x8_three_agents():
   assert ev['pickup'] > 3 and ev['episodes'] > 5, ev
 
 
+def test_doorkey_cross_8x8_five_agents():
+  """DoorKeyEnv16x16's agent count (doorkey.py:95-98) on a smaller grid: the fifth agent's carried object and position"""
+  ev = _cross(8, 5, 2000, seed=11, max_steps=160)
+  assert ev['pickup'] > 3 and ev['episodes'] > 5, ev
+
+
 # ----------------------------------------------------------------------------------------------
 # static base map holding every object type: the mutable-grid step without a generator
 # ----------------------------------------------------------------------------------------------
