@@ -227,10 +227,16 @@ __device__ __forceinline__ void dyn_load(const Params& p, int64_t env0, int lane
 
 template <int A, int K, int PRE>
 __device__ __forceinline__ void dyn_wait(DynIn<A, PRE>& in) {
-  static_assert((A <= 3 || A == 5) && PRE % 16 == 0, "operand lists below");
+  static_assert(A <= 5 && PRE % 16 == 0, "operand lists below");
   if constexpr (A <= 3) {
     asm volatile("s_waitcnt vmcnt(%10)"
                  : "+v"(in.st[0]), "+v"(in.st[1]), "+v"(in.st[2]), "+v"(in.st[3]),
+                   "+v"(in.carry), "+v"(in.act), "+v"(in.aux[0]), "+v"(in.aux[1]), "+v"(in.aux[2]), "+v"(in.aux[3])
+                 : "n"(K)
+                 : "memory");
+  } else if constexpr (A == 4) {
+    asm volatile("s_waitcnt vmcnt(%11)"
+                 : "+v"(in.st[0]), "+v"(in.st[1]), "+v"(in.st[2]), "+v"(in.st[3]), "+v"(in.st[4]),
                    "+v"(in.carry), "+v"(in.act), "+v"(in.aux[0]), "+v"(in.aux[1]), "+v"(in.aux[2]), "+v"(in.aux[3])
                  : "n"(K)
                  : "memory");

@@ -828,11 +828,11 @@ const Variant kVariants[] = {
 struct DynVariant { int A, V; bool full; int pre; kernel_fn fn; };
 #define MG_DYN(A, V, FULL, PRE) {A, FULL ? 0 : V, FULL, PRE, mg_dyn_kernel<A, V, FULL, PRE>}
 const DynVariant kDynVariants[] = {
-    MG_DYN(1, 7, false, 16), MG_DYN(2, 7, false, 16), MG_DYN(3, 7, false, 16), MG_DYN(5, 7, false, 16),
-    MG_DYN(1, 5, false, 16), MG_DYN(2, 5, false, 16), MG_DYN(3, 5, false, 16),
+    MG_DYN(1, 7, false, 16), MG_DYN(2, 7, false, 16), MG_DYN(3, 7, false, 16), MG_DYN(4, 7, false, 16), MG_DYN(5, 7, false, 16),
+    MG_DYN(1, 5, false, 16), MG_DYN(2, 5, false, 16), MG_DYN(3, 5, false, 16), MG_DYN(4, 5, false, 16),
     MG_DYN(1, 5, false, 64), MG_DYN(2, 5, false, 64), MG_DYN(3, 5, false, 64),
     // fully observed kinds (no views; the V parameter is unused)
-    MG_DYN(1, 5, true, 16), MG_DYN(2, 5, true, 16), MG_DYN(3, 5, true, 16),
+    MG_DYN(1, 5, true, 16), MG_DYN(2, 5, true, 16), MG_DYN(3, 5, true, 16), MG_DYN(4, 5, true, 16),
     MG_DYN(1, 5, true, 64), MG_DYN(2, 5, true, 64), MG_DYN(3, 5, true, 64),
 };
 

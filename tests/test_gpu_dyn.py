@@ -55,7 +55,7 @@ def _events(orc, prev_carry):
 
 
 @pytest.mark.parametrize('size,A,n,steps,max_steps', [(5, 1, 1500, 220, 60), (6, 2, 1000, 220, 70),
-                                                      (8, 3, 4096, 260, 90), (16, 1, 300, 120, 50), (8, 5, 1500, 200, 80)])
+                                                      (8, 3, 4096, 260, 90), (16, 1, 300, 120, 50), (8, 5, 1500, 200, 80), (7, 4, 1000, 150, 60)])
 def test_doorkey_free_running_parity(size, A, n, steps, max_steps):
   """Generator, order, respawn, re-placed objects and actions all drawn by Philox on both sides;
   short episodes so that the auto-reset (a fresh layout per env) fires several times."""

@@ -52,7 +52,7 @@ def _cmp(env, orc, what, step=True):
 
 @pytest.mark.parametrize('size,A,goals,clutter,n,steps,max_steps', [(6, 3, 3, 0, 2000, 150, 40), (8, 3, 1, 5, 1500, 150, 50),
                                                                    (15, 3, 3, 0, 700, 120, 60), (10, 2, 2, 10, 500, 100, 45),
-                                                                   (12, 1, 3, 10, 300, 100, 45), (12, 3, 5, 0, 600, 100, 45), (7, 2, 6, 3, 600, 100, 30)])
+                                                                   (12, 1, 3, 10, 300, 100, 45), (12, 3, 5, 0, 600, 100, 45), (7, 2, 6, 3, 600, 100, 30), (8, 4, 2, 4, 600, 100, 40)])
 def test_meetup_free_running_parity(size, A, goals, clutter, n, steps, max_steps):
   _need_gpu()
   env, orc = _make('meetup', size, A, n, max_steps, seed=size + goals, V=7, n_goals=goals, n_clutter=clutter)
@@ -78,7 +78,9 @@ def test_meetup_free_running_parity(size, A, goals, clutter, n, steps, max_steps
 @pytest.mark.parametrize('size,A,V,rand_goal,clutter,lava,n,steps,max_steps', [(15, 3, 5, 1, 25, False, 2000, 160, 50),
                                                                               (6, 1, 5, 1, 5, False, 1500, 150, 30),
                                                                               (10, 2, 7, 0, 15, True, 1000, 150, 40),
-                                                                              (6, 1, 5, 0, 4, True, 1000, 120, 30)])
+                                                                              (6, 1, 5, 0, 4, True, 1000, 120, 30),
+                                                                              (8, 4, 5, 1, 6, False, 1000, 120, 30),
+                                                                              (9, 5, 7, 1, 6, False, 800, 120, 30)])
 def test_cluttered_random_layout_parity(size, A, V, rand_goal, clutter, lava, n, steps, max_steps):
   """Every env draws its own layout at every reset; the v8 shaper measures to the env's own goal."""
   _need_gpu()
