@@ -20,14 +20,15 @@ generate_trajectory_video.py:180-241).  Purpose: make bit-exact parity reproduci
   recorded episode) and compares every recorded output; used by tests and by the CLI.
 
 Fixture schema (E episodes, T = longest episode, A agents, V view size):
-  meta          json: schema, kind ('static' | 'doorkey' | 'cluttered' | 'meetup'), width, height, n_agents, view_size,
+  meta          json: schema, kind ('static' | 'doorkey' | 'cluttered' | 'meetup' | 'fourrooms'), width, height, n_agents, view_size,
                 max_steps, see_through_walls, competitive, shaping ('none' | 'v8' | 'v7'), source
   cells         uint8[H, W, 3]            layout (kind 'static'), encode() triples
   length        int32[E]                  steps recorded for the episode (it ended with done, or at T)
   spawn         int8[E, A, 4]             (x, y, dir, 0) accepted at reset
   gen           int8[E, 4]                DoorKey (split_idx, door_idx, key_x, key_y)
   scatter       int8[E, n_obj, 2]         cluttered / meetup: accepted (x, y) of every scattered object in draw order
-                                          (meta then also holds n_goals, n_clutter, walls_are_lava)
+                                          (meta then also holds n_goals, n_clutter, walls_are_lava); fourrooms: three pairs =
+                                          (top gap y, left gap x), (right gap x, bottom gap y), goal (x, y); meta holds two_rooms
   actions       uint8[E, T, A]
   order         uint8[E, T, A]            order[e, t, k] = agent acting k-th
   respawn       int8[E, T, A, 4]          (x, y, dir, 0) if agent a finished in that step, x = -1 otherwise
@@ -106,6 +107,25 @@ class Recorder:
       g[:] = (split, doors[0], keys[-1][0], keys[-1][1])
     return g
 
+  def _fourrooms_gaps(self):
+    """The wall gaps FourRoomsEnv._gen_grid drew (fourrooms.py:66-90), read back from the generated grid: they are
+    _rand_int draws, not placements.  A gap the reference did not carve (x <= 1, x >= W-1, y >= H-1) leaves no trace;
+    the value recorded for it is one that is not carved on replay either."""
+    e = self.env
+    W, H = e.width, e.height
+    rw, rh = W // 2, H // 2
+
+    def is_wall(x, y):
+      c = e.grid.get(x, y)
+      return c is not None and c.encode()[0] == 2
+
+    top = [y for y in range(1, rh) if not is_wall(rw, y)]
+    left = [x for x in range(1, rw) if not is_wall(x, rh)]
+    right = [x for x in range(rw + 1, 2 * rw) if not is_wall(x, rh)]
+    bottom = [y for y in range(rh + 1, 2 * rh) if not is_wall(rw, y)]
+    pick = lambda found, uncarved: found[0] if len(found) == 1 else uncarved
+    return [[pick(top, 1), pick(left, 1)], [pick(right, 2 * rw - 1), pick(bottom, 2 * rh - 1)]]
+
   def episode(self, policy, max_len):
     """policy(env, obs, t) -> list of A ints.  Records until done or max_len steps."""
     e, A = self.env, self.A
@@ -117,7 +137,9 @@ class Recorder:
     for a, x, y, d in self._agents[-A:]:
       spawn[a] = (x, y, d, 0)
     scatter = np.array([[x, y] for (_, x, y) in self._objects], np.int8).reshape(-1, 2)
-    if self.kind not in ('cluttered', 'meetup'):       # (fourrooms gaps are not place_obj calls: not recordable this way)
+    if self.kind == 'fourrooms':
+      scatter = np.array(self._fourrooms_gaps() + [[self._objects[-1][1], self._objects[-1][2]]], np.int8)
+    elif self.kind not in ('cluttered', 'meetup'):
       scatter = np.zeros((0, 2), np.int8)
     out = dict(spawn=spawn, gen=self._gen(), scatter=scatter, actions=[], order=[], respawn=[], objdrop=[], env_reward=[], shaped_reward=[],
                done=[], obs_image=[np.stack(obs['image'])], obs_dir=[np.array(obs['direction'], np.uint8)])
@@ -228,7 +250,9 @@ def replay_on_device(rec, device=0, check_state=True):
     env = BatchedMultiGrid(None, kind='doorkey', size=m['width'], **kw)
   elif m['kind'] in ('cluttered', 'meetup'):
     env = BatchedMultiGrid(None, kind=m['kind'], size=m['width'], n_goals=m['n_goals'], n_clutter=m['n_clutter'],
-                           walls_are_lava=bool(m.get('walls_are_lava', False)), **kw)
+                           walls_are_lava=m.get('walls_are_lava', False), **kw)
+  elif m['kind'] == 'fourrooms':
+    env = BatchedMultiGrid(None, kind='fourrooms', size=m['width'], two_rooms=bool(m.get('two_rooms', False)), **kw)
   else:
     env = BatchedMultiGrid(rec['cells'], **kw)
   dev = env.device
@@ -246,7 +270,7 @@ def replay_on_device(rec, device=0, check_state=True):
     return env.obs_image.cpu().numpy().transpose(1, 0, 2, 3, 4)
 
   try:
-    if m['kind'] in ('cluttered', 'meetup'):
+    if m['kind'] in ('cluttered', 'meetup', 'fourrooms'):
       env.reset(spawn=am(rec['spawn']), scatter=rec['scatter'])
     elif env.mutable_grid:
       env.reset(spawn=am(rec['spawn']), gen=torch.from_numpy(rec['gen']).to(dev) if m['kind'] == 'doorkey' else None)
@@ -277,8 +301,8 @@ def replay_on_device(rec, device=0, check_state=True):
         cmp('agent_pos', env.agent_pos.cpu().numpy().transpose(1, 0, 2), rec['agent_pos'][:, t + 1], live)
         cmp('agent_dir', env.agent_dir.cpu().numpy().T, rec['agent_dir'][:, t + 1], live)
         if env.mutable_grid and 'carry' in rec:
-          c = env.carry.cpu().numpy().view(np.uint32)
-          got = np.stack([(c >> (8 * a)) & 255 for a in range(A)], axis=1)
+          c = env.carry.cpu().numpy().view(np.uint32).reshape(E, -1)      # one word per env, two with five agents
+          got = np.stack([(c[:, a // 4] >> (8 * (a % 4))) & 255 for a in range(A)], axis=1)
           cmp('carry', got, rec['carry'][:, t + 1], live)
     err = env.check_errors()
     if err:

@@ -1,4 +1,5 @@
-"""Records tests/golden/replay_doorkey_6x6.npz, replay_playground_9x9.npz and replay_meetup_8x8.npz with multigrid_amd.recorder
+"""Records tests/golden/replay_doorkey_6x6.npz, replay_playground_9x9.npz, replay_meetup_8x8.npz, replay_fourrooms_9x9.npz and
+replay_tworooms_6x6.npz with multigrid_amd.recorder
 from the pure-Python object-style restatement (oracle/py_ref_env.py), driven the way the reference
 drives its env (env-local PCG64 for placement, global np.random.shuffle for the agent order).
 
@@ -132,6 +133,19 @@ def main():
   rec = recorder.stack_episodes(eps, meta)
   recorder.save(os.path.join(here, 'replay_meetup_8x8.npz'), rec)
   print('meetup', 'lengths', rec['length'].tolist(), 'nonzero rewards', int((rec['env_reward'] != 0).sum()))
+
+  for name, size, A, two, seed, episodes in (('replay_fourrooms_9x9.npz', 9, 2, False, 41, 16), ('replay_tworooms_6x6.npz', 6, 1, True, 43, 24)):
+    env = py_ref_env.PyFourRoomsEnv(grid_size=size, n_agents=A, view_size=5, two_rooms=two, seed=seed, order_fn=global_shuffle_order(A))
+    env.max_steps = 60
+    np.random.seed(seed + 1)
+    rng = np.random.RandomState(seed + 2)
+    r = recorder.Recorder(env, shaper=Shaper(env), kind='fourrooms')
+    eps = [r.episode(lambda e, obs, t: rng.choice(7, size=A, p=[.15, .15, .5, .05, .05, .05, .05]), 60) for _ in range(episodes)]
+    meta = dict(kind='fourrooms', width=size, height=size, n_agents=A, view_size=5, max_steps=60, see_through_walls=False,
+                competitive=bool(env.competitive), shaping='v8', two_rooms=two, source='oracle/py_ref_env.py restatement (not cxh42 code)')
+    rec = recorder.stack_episodes(eps, meta)
+    recorder.save(os.path.join(here, name), rec)
+    print(name, 'goal touches', int((rec['env_reward'] > 0).sum()), 'distinct layouts', len({tuple(sc.ravel()) for sc in rec['scatter']}))
 
 
 if __name__ == '__main__':

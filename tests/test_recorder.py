@@ -14,7 +14,8 @@ from multigrid_amd import recorder
 from oracle import c_oracle, py_ref_env
 
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
-FIXTURES = ['replay_cluttered_fixed_15x15.npz', 'replay_doorkey_6x6.npz', 'replay_playground_9x9.npz', 'replay_meetup_8x8.npz']
+FIXTURES = ['replay_cluttered_fixed_15x15.npz', 'replay_doorkey_6x6.npz', 'replay_playground_9x9.npz', 'replay_meetup_8x8.npz',
+            'replay_fourrooms_9x9.npz', 'replay_tworooms_6x6.npz']
 
 
 def replay_on_oracle(rec):
@@ -27,8 +28,9 @@ def replay_on_oracle(rec):
     env = c_oracle.OracleEnv(rec.get('cells') if m['kind'] == 'static' else None, W=m['width'], H=m['height'], A=A,
                              V=m['view_size'], max_steps=m['max_steps'], shaping=(2 if m.get('shaping') == 'v7' else 1) if shaped else 0,
                              kind=m['kind'],
-                             n_goals=m.get('n_goals', 0), n_clutter=m.get('n_clutter', 0), lava=m.get('walls_are_lava', False))
-    if m['kind'] in ('cluttered', 'meetup'):
+                             n_goals=m.get('n_goals', 0), n_clutter=m.get('n_clutter', 0), lava=m.get('walls_are_lava', False),
+                             two_rooms=bool(m.get('two_rooms', False)))
+    if m['kind'] in ('cluttered', 'meetup', 'fourrooms'):
       obs = env.reset(spawn=rec['spawn'][e, :, :3], scatter=rec['scatter'][e])
     else:
       obs = env.reset(spawn=rec['spawn'][e, :, :3], gen=rec['gen'][e] if m['kind'] == 'doorkey' else None)
@@ -53,7 +55,7 @@ def replay_on_oracle(rec):
 @pytest.mark.parametrize('name', FIXTURES)
 def test_fixture_replays_on_the_c_oracle(name):
   rec = recorder.load(os.path.join(GOLDEN, name))
-  assert rec['meta']['kind'] in ('static', 'doorkey', 'cluttered', 'meetup')
+  assert rec['meta']['kind'] in ('static', 'doorkey', 'cluttered', 'meetup', 'fourrooms')
   assert replay_on_oracle(rec) == 0
 
 
