@@ -347,6 +347,12 @@ class _V7Shaper:
 
 
 def record_reference(reference_path, env_id, episodes, seed=0, shaping='v8', max_len=None):
+  """Records `episodes` random-policy episodes of the real reference env `env_id`.  Covers the ids whose reset is one of the
+  device kinds with random starts (Cluttered family, DoorKey, Meetup, FourRooms / TwoRooms, Empty-Random, WallsAreLava) in
+  their multi-agent container shapes; the `*-Minigrid-*` ids (unwrapped image / scalar reward) and EmptyEnv's fixed starts
+  (displacement chains move agents that did not finish) are not handled by this leg yet."""
+  if 'Minigrid' in env_id:
+    raise SystemExit('recording the *-Minigrid-* container shapes is not implemented; record the multi-agent id of the same class')
   import importlib
   import sys
   sys.path.insert(0, reference_path)
@@ -357,7 +363,17 @@ def record_reference(reference_path, env_id, episodes, seed=0, shaping='v8', max
     raise SystemExit('recording from the reference needs gym==0.23.1 and gym-minigrid==1.0.3 (and numpy<1.24): %s' % e)
   env = gym.make(env_id)
   base = env.unwrapped
-  kind = 'doorkey' if 'DoorKey' in env_id else 'static'
+  # which generator the id runs at reset (the device env of the same kind replays the recording)
+  if 'DoorKey' in env_id:
+    kind = 'doorkey'
+  elif 'Meetup' in env_id:
+    kind = 'meetup'
+  elif 'Rooms' in env_id and 'Nine' not in env_id and 'Sixteen' not in env_id:
+    kind = 'fourrooms'
+  elif ('Cluttered' in env_id and 'Fixed' not in env_id) or 'WallsAreLava' in env_id or getattr(base, 'randomize_goal', False):
+    kind = 'cluttered'
+  else:
+    kind = 'static'
   shaper = None
   if shaping == 'v8':
     shaper = _V8Shaper(importlib.import_module('v8_robust_ppo'), base)
@@ -378,6 +394,12 @@ def record_reference(reference_path, env_id, episodes, seed=0, shaping='v8', max
   meta = dict(kind=kind, width=base.width, height=base.height, n_agents=base.n_agents, view_size=base.agent_view_size,
               max_steps=base.max_steps, see_through_walls=bool(base.see_through_walls), competitive=bool(base.competitive),
               shaping=shaping or 'none', source='reference %s via gym.make(%r)' % (reference_path, env_id))
+  if kind in ('cluttered', 'meetup'):
+    lava = 'lavawall' if 'WallsAreLava' in env_id else bool(getattr(base, 'walls_are_lava', False))
+    meta.update(n_goals=int(getattr(base, 'n_goals', 1 if getattr(base, 'randomize_goal', False) else 0)),
+                n_clutter=int(getattr(base, 'n_clutter', 0)), walls_are_lava=lava)
+  if kind == 'fourrooms':
+    meta.update(two_rooms=bool(getattr(base, 'two_rooms', False)))
   return stack_episodes(eps, meta, cells)
 
 
