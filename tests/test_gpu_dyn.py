@@ -287,3 +287,48 @@ def test_sharding_invariance_of_generated_kinds(env_id):
       assert torch.equal(whole.obs_image[:, sl], part.obs_image)
   for e in [whole] + parts:
     e.close()
+
+
+@pytest.mark.parametrize('env_id,n', [('MultiGrid-DoorKey-8x8-v0', 1 << 20), ('MultiGrid-Cluttered-v0', 1 << 19)])
+def test_full_size_invariants_of_generated_kinds(env_id, n):
+  """The bench shapes of the mutable-grid kernel (up to 1,048,576 envs, far more than the oracle can follow): properties
+  that hold for every env at every step whatever the draws were.  DoorKey: exactly one yellow key, on the grid or in
+  an agent's hands (multigrid.py:926-951 moves it, :827-829 re-places it); at most one door, and only in the split
+  column; exactly one goal at (W-2, H-2).  Cluttered: one goal, 25 walls inside the border.  Both: the border is
+  wall, agents stand on distinct cells that hold no object, nothing was reported in the error word."""
+  _need_gpu()
+  import multigrid_amd
+  env = multigrid_amd.make_batched(env_id, n, seed=20260101)
+  W, H, A = env.width, env.height, env.n_agents
+  env.reset()
+  for t in range(60):
+    env.step_random()
+    if t not in (0, 17, 59):
+      continue
+    k = env.grid_kinds().long()                                   # [n, H, W]
+    border = torch.ones((H, W), dtype=torch.bool, device=k.device)
+    border[1:-1, 1:-1] = False
+    assert bool((k[:, border] == 21).all())                       # grey wall = 2*8 + 5
+    assert bool(((k == 65).sum(dim=(1, 2)) == 1).all())           # green goal = 8*8 + 1
+    pos = env.agent_pos.long()                                    # [A, n, 2]
+    cell = pos[..., 1] * W + pos[..., 0]
+    under = torch.gather(k.reshape(n, -1), 1, cell.t())           # what the grid holds under each agent
+    assert bool((under == 0).all())
+    for a in range(A):
+      for b in range(a + 1, A):
+        assert bool((cell[a] != cell[b]).all())
+    if 'DoorKey' in env_id:
+      carry = env.carry.long().reshape(n, -1)[:, 0]
+      carried = sum(((carry >> (8 * a)) & 255) == 44 for a in range(A))     # yellow key = 5*8 + 4
+      assert bool((((k == 44).sum(dim=(1, 2)) + carried) == 1).all())
+      assert bool((k[:, H - 2, W - 2] == 65).all())
+      doors = k >= 128
+      assert bool((doors.sum(dim=(1, 2)) <= 1).all())
+      split = (env.step_state.long() >> 24) & 63                            # the spawn region's width = the wall column
+      col = torch.gather(doors.any(dim=1).long(), 1, split.reshape(n, 1))   # a door, if any, sits in that column
+      assert bool((col.reshape(n) == doors.any(dim=(1, 2)).long()).all())
+    else:
+      inner_walls = (k[:, 1:-1, 1:-1] == 21).sum(dim=(1, 2))
+      assert bool((inner_walls == 25).all())
+  assert env.check_errors() == 0
+  env.close()
