@@ -215,3 +215,33 @@ def test_scatter_registry_ids():
   obs = env.reset()
   assert obs['image'][0].shape == (5, 5, 3) and env.grid.get(0, 0).type == 'wall'
   env.close()
+
+
+def test_full_size_meetup_invariants():
+  """Meetup-Random-8x8 at 262,144 envs: three locked red doors and five walls inside the border whatever happened
+  (no key exists, so no door ever opens); the fully observed image shows exactly the A agents, on their cells, with their
+  ids and directions (Agent.encode, multigrid.py:137-139) and is otherwise the grid's encoding."""
+  _need_gpu()
+  import multigrid_amd
+  n = 1 << 18
+  env = multigrid_amd.make_batched('MultiGrid-Meetup-Random-8x8-v0', n, seed=77)
+  W, H, A = env.width, env.height, env.n_agents
+  env.reset()
+  for t in range(40):
+    env.step_random()
+    if t not in (0, 39):
+      continue
+    k = env.grid_kinds().long()
+    assert bool(((k == 128 + 0 * 4 + 2).sum(dim=(1, 2)) == 3).all())
+    assert bool(((k[:, 1:-1, 1:-1] == 21).sum(dim=(1, 2)) == 5).all())
+    img = env.obs_full.long()                                       # [n, W, H, 3], [x][y]
+    assert bool(((img[..., 0] == 10).sum(dim=(1, 2)) == A).all())
+    pos, d = env.agent_pos.long(), env.agent_dir.long()             # [A, n, 2], [A, n]
+    idx = torch.arange(n, device=img.device)
+    for a in range(A):
+      cell = img[idx, pos[a, :, 0], pos[a, :, 1]]
+      assert bool((cell[:, 0] == 10).all()) and bool((cell[:, 1] == a).all()) and bool((cell[:, 2] == d[a]).all())
+    walls = img[..., 0] == 2
+    assert bool((walls.permute(0, 2, 1) == (k == 21)).all())        # image is [x][y], the grid [y][x]
+  assert env.check_errors() == 0
+  env.close()
