@@ -958,6 +958,18 @@ size_t lds_fixed_bytes(const mg_handle* h, bool table) {
 // Launch geometry: workgroups are persistent and stride over the 64-env chunks.  Waves per
 // workgroup are chosen so that (a) the LDS tables + per-wave staging fit 160 KB and (b) a small
 // batch still spreads over all CUs.
+// Which shared-map kernel a launch runs.  Up to kUpfront chunks per resident wave (1,048,576 envs on 256 CUs) the
+// persistent table kernel is fastest: its whole batch is launch-resident and it reads everything before it writes.
+// Beyond that the working set no longer lives in the Infinity Cache, and a write stream then runs ~20 % faster when
+// short-lived workgroups write their chunks in dispatch order than when persistent waves stride over the buffers
+// (tools/wstream.cpp).  Only the generic kernels can be launched that way — they have next to no
+// per-workgroup prologue — so a large batch takes them, one chunk per wave, unless the caller forced a path.
+bool launch_uses_table(const mg_handle* h) {
+  if (!h->use_table) return false;
+  if (h->cfg.kernel_path == MG_PATH_TABLE) return true;
+  return h->n_chunks <= (int64_t)h->n_cu * 16 * kUpfront;
+}
+
 void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid_out, size_t* lds_out) {
   const int rowb = h->cfg.view_size * h->cfg.view_size * 3;
   const size_t fixed = lds_fixed_bytes(h, table), per_wave = (size_t)kWave * rowb;
@@ -969,7 +981,8 @@ void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid
   per_cu = std::max(1, std::min(per_cu, 32 / nw));
   const int64_t blocks = (h->n_chunks + nw - 1) / nw;
   *nw_out = nw;
-  *grid_out = (unsigned)std::min<int64_t>(blocks, (int64_t)h->n_cu * per_cu);
+  // generic kernels: one chunk per wave (a workgroup per nw chunks, dispatched in address order); table kernels: persistent
+  *grid_out = table ? (unsigned)std::min<int64_t>(blocks, (int64_t)h->n_cu * per_cu) : (unsigned)blocks;
   if (const char* e = getenv("MG_DEBUG_GRID"))   // tests only: few workgroups => many chunks per wave
     *grid_out = (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, atoi(e)));
   *lds_out = lds;
@@ -1001,6 +1014,8 @@ void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* l
   const int64_t blocks = (h->n_chunks + nw - 1) / nw;
   *nw_out = nw;
   *grid_out = (unsigned)std::min<int64_t>(blocks, (int64_t)h->n_cu * per_cu);
+  if (const char* e = getenv("MG_DEBUG_GRID"))   // tuning experiments / tests only
+    *grid_out = (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, atoi(e)));
   *lds_out = lds;
 }
 
@@ -1044,9 +1059,10 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     return MG_OK;
   }
   if (objdrop || reset_gen || scatter) return fail(MG_EINVAL, "objdrop / gen / scatter injection needs a mutable-grid handle");
-  launch_geometry(h, h->use_table, &nw, &grid, &lds);
+  const bool table = launch_uses_table(h);
+  launch_geometry(h, table, &nw, &grid, &lds);
   const int fast = (op == OP_STEP && !order && !respawn && !reset_spawn && !random_actions && !h->buf.env_reward) ? 1 : 0;
-  hipLaunchKernelGGL(h->use_table ? h->var->table[fast] : h->var->generic[fast], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
+  hipLaunchKernelGGL(table ? h->var->table[fast] : h->var->generic[fast], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
   HIP_TRY(hipGetLastError());
   return MG_OK;
 }
@@ -1520,8 +1536,8 @@ int mg_get_launch_info(mg_handle* h, int32_t* path, int32_t* block_threads, int3
   if (!h) return fail(MG_EINVAL, "null handle");
   int nw; unsigned grid; size_t lds;
   if (h->dynamic) dyn_geometry(h, &nw, &grid, &lds);
-  else launch_geometry(h, h->use_table, &nw, &grid, &lds);
-  if (path) *path = h->use_table ? MG_PATH_TABLE : MG_PATH_GENERIC;
+  else launch_geometry(h, launch_uses_table(h), &nw, &grid, &lds);
+  if (path) *path = launch_uses_table(h) ? MG_PATH_TABLE : MG_PATH_GENERIC;
   if (block_threads) *block_threads = nw * kWave;
   if (grid_blocks) *grid_blocks = (int32_t)grid;
   if (lds_bytes) *lds_bytes = (int32_t)lds;

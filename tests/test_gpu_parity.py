@@ -121,7 +121,8 @@ def test_v7_shaper_parity(cluttered_cells, fast):
 
 @pytest.mark.parametrize('path,n,grid,nw', [('table', 3000, None, None),      # all inputs fetched up front
                                             ('table', 20000, 3, 4),          # rolling prefetch, 26 chunks per wave
-                                            ('generic', 20000, 2, 4), ('table', 70000, None, None)])
+                                            ('generic', 20000, 2, 4), ('table', 70000, None, None),
+                                            ('generic', 20000, None, None)])    # one chunk per wave, 79 workgroups
 def test_fast_instantiation_parity(cluttered_cells, monkeypatch, path, n, grid, nw):
   """The FAST instantiation (free-running step, actions from HBM, no env_reward output — the one
   bench.py times) against the oracle, on both of its chunk loops: launch-resident batches fetch
@@ -355,6 +356,42 @@ def test_lavawall_cells_on_a_static_map(empty_cells):
   assert (img[..., 0] == 9).any() and not ((img[..., 0] == 9) & (img[..., 1] == 5)).any()   # red lava shows, LavaWall never does
   assert env.check_errors() == 0 and orc.errors() == 0
   env.close()
+
+
+def test_large_batch_takes_the_generic_kernels_one_chunk_per_wave(cluttered_cells):
+  """Beyond four chunks per resident wave (1,048,576 envs on 256 CUs) a shared-map handle switches from the persistent
+  table kernel to the generic one launched one chunk per wave (in-order short-lived workgroups write faster
+  once the working set exceeds the Infinity Cache).  Same results as two half-size handles, which stay on the table path."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  n = 1_200_000
+  whole = BatchedMultiGrid(cluttered_cells, n_envs=n, seed=123)
+  info = whole.launch_info()
+  if info['grid_blocks'] <= 256:
+    pytest.skip('fewer chunks than the switch-over on this device')
+  assert info['path'] == 'generic' and info['grid_blocks'] == (whole.stride // 64 + 3) // 4
+  half = n // 2
+  lo = BatchedMultiGrid(cluttered_cells, n_envs=half, seed=123, env_id_base=0)
+  hi = BatchedMultiGrid(cluttered_cells, n_envs=half, seed=123, env_id_base=half)
+  assert lo.launch_info()['path'] == 'table'
+  g = torch.Generator(device=whole.device)
+  g.manual_seed(5)
+  for e in (whole, lo, hi):
+    e.reset()
+  for t in range(14):
+    act = torch.randint(0, 7, (n, 4), dtype=torch.uint8, device=whole.device, generator=g)
+    whole.actions[:n] = act
+    lo.actions[:half] = act[:half]
+    hi.actions[:half] = act[half:]
+    for e in (whole, lo, hi):
+      e.step()
+  torch.cuda.synchronize()
+  assert torch.equal(whole.obs_image[:, :half], lo.obs_image) and torch.equal(whole.obs_image[:, half:n], hi.obs_image)
+  assert torch.equal(whole.reward[:, :half], lo.reward) and torch.equal(whole.reward[:, half:n], hi.reward)
+  assert torch.equal(whole.agent_state[:, half:n], hi.agent_state) and torch.equal(whole.done[:half], lo.done)
+  assert whole.check_errors() == 0 and lo.check_errors() == 0 and hi.check_errors() == 0
+  for e in (whole, lo, hi):
+    e.close()
 
 
 def test_error_reporting(cluttered_cells):
