@@ -338,7 +338,7 @@ __device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uin
       v.y = __builtin_amdgcn_alignbyte(s2, s1, m[u]);
       v.z = __builtin_amdgcn_alignbyte(s3, s2, m[u]);
       v.w = __builtin_amdgcn_alignbyte(s4, s3, m[u]);
-      if (q + u * kWave < nv) dst[q + u * kWave] = v;
+      if (q + u * kWave < nv) store_vec16(dst + q + u * kWave, v, p.nt_obs != 0);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -669,7 +669,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       uint32_t s[NW + 1];
       uint64_t vm;
       dyn_view<V>(p, g, lut, pd_get(pd, a), (uint32_t)(carry >> (8 * a)) & 255u, s, vm);
-      emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB);
+      emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB, p.nt_obs != 0);
     }
   }
 #endif

@@ -66,7 +66,8 @@ template <int V> struct ViewGeom {
 
 struct Params {
   int32_t W, H, max_steps, see_through, competitive, shaping, auto_reset, dd_bytes;
-  int32_t op, random_actions, PW, PH, n_entries, reserved;
+  int32_t op, random_actions, PW, PH, n_entries;
+  int32_t nt_obs;              // obs images leave with non-temporal stores (launch()'s streaming rule)
   int64_t n_envs, stride, n_chunks;
   uint64_t gid_base, t;
   uint32_t seed_lo, seed_hi;
@@ -294,10 +295,20 @@ __device__ __forceinline__ void table_view(const Params& p, const uint32_t* tabl
   vm = t[NW];
 }
 
+// One 16-byte obs vector to HBM.  nt (wave-uniform, from the launch) = non-temporal: the line is not kept in L2 / the
+// Infinity Cache.  A batch whose outputs exceed the cache is rewritten every step without ever being re-read in
+// between, so keeping the lines only costs evictions (4M envs: 216 -> 192 us); a launch-resident batch is faster
+// with ordinary stores (1M envs, table kernel: 51.5 vs 57.7 us), hence a run-time choice (launch()).
+__device__ __forceinline__ void store_vec16(uint4* dst, const uint4 v, bool nt) {
+  typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+  if (nt) __builtin_nontemporal_store(v4{v.x, v.y, v.z, v.w}, reinterpret_cast<v4*>(dst));
+  else *dst = v;
+}
+
 // Stage the 64 images of this wave in LDS and stream them to HBM as one contiguous chunk.
 template <int A, int V>
 __device__ __forceinline__ void emit_obs(pd_t<A> pd, int a, uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t vm,
-                                         uint32_t* stage, int lane, uint8_t* gchunk) {
+                                         uint32_t* stage, int lane, uint8_t* gchunk, bool nt) {
   constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
   const uint32_t me = pd_get(pd, a);
   const int x = aw_x(me), y = aw_y(me), d = aw_d(me);
@@ -351,7 +362,7 @@ __device__ __forceinline__ void emit_obs(pd_t<A> pd, int a, uint32_t (&s)[ViewGe
 #if MG_ABL == 1
     if (idx < NV) { uint4 v = src[idx]; asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
 #else
-    if (idx < NV) dst[idx] = src[idx];
+    if (idx < NV) store_vec16(dst + idx, src[idx], nt);
 #endif
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -712,7 +723,7 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
     uint64_t vm;
     if (TAB) table_view<V>(p, table, cidx, pd_get(pd, a), s, vm);
     else static_view<V>(p, map, pd_get(pd, a), s, vm);
-    emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB);
+    emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB, p.nt_obs != 0);
   }
 #endif
 }
@@ -970,6 +981,21 @@ bool launch_uses_table(const mg_handle* h) {
   return h->n_chunks <= (int64_t)h->n_cu * 16 * kUpfront;
 }
 
+// Whether the obs images leave with non-temporal stores (store_vec16): when a launch writes more obs than the 256 MB
+// Infinity Cache can usefully hold.  Shared-map kernels: beyond the launch-resident batch, the same boundary as
+// launch_uses_table (1.3M envs 67.4 -> 61.8 us, 2M 114.3 -> 96.4, 4M 216.1 -> 192.3, 8M 427 -> 412; at 1M the resident
+// table kernel loses: 51.5 -> 57.7 us).  Mutable-grid kernels: from 192 MiB of obs per launch (DoorKey-8x8x3 at 1M envs
+// 167.3 -> 148.6 us, Meetup-15x15x3 307.4 -> 291.2; no difference either way below that).  tools/nt_sweep.sh, DESIGN §6.
+bool launch_streams_obs(const mg_handle* h) {
+  if (const char* e = getenv("MG_DEBUG_NT")) return atoi(e) != 0;   // tuning experiments only
+  if (h->dynamic) {
+    const mg_config& c = h->cfg;
+    const int64_t per_env = h->full_obs ? (int64_t)c.width * c.height * 3 : (int64_t)c.n_agents * c.view_size * c.view_size * 3;
+    return h->stride * per_env >= ((int64_t)192 << 20);
+  }
+  return h->n_chunks > (int64_t)h->n_cu * 16 * kUpfront;
+}
+
 void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid_out, size_t* lds_out) {
   const int rowb = h->cfg.view_size * h->cfg.view_size * 3;
   const size_t fixed = lds_fixed_bytes(h, table), per_wave = (size_t)kWave * rowb;
@@ -1049,6 +1075,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   p.gx = h->gx; p.gy = h->gy; p.LW = h->LW; p.LH = h->LH;
   p.fixed_mode = h->fixed_mode; p.fixed_pd = h->fixed_pd; p.fixed_pd_hi = h->fixed_pd_hi; p.reserved_pd = 0;
   p.scatter = reinterpret_cast<const uint16_t*>(scatter); p.aux = h->aux; p.obs_full = h->obs_full;
+  p.nt_obs = launch_streams_obs(h) ? 1 : 0;
   int nw; unsigned grid; size_t lds;
   DeviceGuard g(h->device);
   if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
