@@ -966,6 +966,12 @@ size_t lds_fixed_bytes(const mg_handle* h, bool table) {
   return (b + 15) / 16 * 16;
 }
 
+// Debug / tuning overrides (tests, tools/): an unset or empty variable means "no override".
+const char* debug_env(const char* name) {
+  const char* e = getenv(name);
+  return (e && *e) ? e : nullptr;
+}
+
 // Launch geometry: workgroups are persistent and stride over the 64-env chunks.  Waves per
 // workgroup are chosen so that (a) the LDS tables + per-wave staging fit 160 KB and (b) a small
 // batch still spreads over all CUs.
@@ -987,7 +993,7 @@ bool launch_uses_table(const mg_handle* h) {
 // table kernel loses: 51.5 -> 57.7 us).  Mutable-grid kernels: from 192 MiB of obs per launch (DoorKey-8x8x3 at 1M envs
 // 167.3 -> 148.6 us, Meetup-15x15x3 307.4 -> 291.2; no difference either way below that).  tools/nt_sweep.sh, DESIGN §6.
 bool launch_streams_obs(const mg_handle* h) {
-  if (const char* e = getenv("MG_DEBUG_NT")) return atoi(e) != 0;   // tuning experiments only
+  if (const char* e = debug_env("MG_DEBUG_NT")) return atoi(e) != 0;   // tuning experiments only
   if (h->dynamic) {
     const mg_config& c = h->cfg;
     const int64_t per_env = h->full_obs ? (int64_t)c.width * c.height * 3 : (int64_t)c.n_agents * c.view_size * c.view_size * 3;
@@ -1000,7 +1006,7 @@ void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid
   const int rowb = h->cfg.view_size * h->cfg.view_size * 3;
   const size_t fixed = lds_fixed_bytes(h, table), per_wave = (size_t)kWave * rowb;
   int nw = table ? 16 : 4;
-  if (const char* e = getenv("MG_DEBUG_NW")) nw = atoi(e);   // tuning experiments only
+  if (const char* e = debug_env("MG_DEBUG_NW")) nw = atoi(e);   // tuning experiments only
   while (nw > 1 && (fixed + nw * per_wave > (size_t)kLdsLimit || h->n_chunks < (int64_t)h->n_cu * nw)) nw >>= 1;
   const size_t lds = fixed + nw * per_wave;
   int per_cu = (int)((size_t)kLdsLimit / lds);
@@ -1009,7 +1015,7 @@ void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid
   *nw_out = nw;
   // generic kernels: one chunk per wave (a workgroup per nw chunks, dispatched in address order); table kernels: persistent
   *grid_out = table ? (unsigned)std::min<int64_t>(blocks, (int64_t)h->n_cu * per_cu) : (unsigned)blocks;
-  if (const char* e = getenv("MG_DEBUG_GRID"))   // tests only: few workgroups => many chunks per wave
+  if (const char* e = debug_env("MG_DEBUG_GRID"))   // tests only: few workgroups => many chunks per wave
     *grid_out = (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, atoi(e)));
   *lds_out = lds;
 }
@@ -1040,7 +1046,7 @@ void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* l
   const int64_t blocks = (h->n_chunks + nw - 1) / nw;
   *nw_out = nw;
   *grid_out = (unsigned)std::min<int64_t>(blocks, (int64_t)h->n_cu * per_cu);
-  if (const char* e = getenv("MG_DEBUG_GRID"))   // tuning experiments / tests only
+  if (const char* e = debug_env("MG_DEBUG_GRID"))   // tuning experiments / tests only
     *grid_out = (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, atoi(e)));
   *lds_out = lds;
 }
