@@ -26,7 +26,7 @@
 #include <string.h>
 #include <math.h>
 
-#define MAXW 32
+#define MAXW 64
 #define MAXA 8
 #define MAXV 9
 

@@ -674,3 +674,75 @@ def test_fixed_start_at_reset_maze_parity():
 def multigrid_amd_make(env_id):
   import multigrid_amd
   return multigrid_amd.make_batched(env_id, 256, seed=1)
+
+
+def _sprinkled(W, H, goal, n_walls, n_lava, seed):
+  """Bordered W x H layout with a goal, scattered walls and a few lava cells (synthetic; no reference counterpart)."""
+  from multigrid_amd import layouts
+  cells = layouts.empty_bordered(W, H, goal=goal)
+  rng = np.random.RandomState(seed)
+  for k in range(n_walls + n_lava):
+    x, y = int(rng.randint(1, W - 1)), int(rng.randint(1, H - 1))
+    if goal is None or (x, y) != tuple(goal):
+      cells[y, x] = (layouts.WALL, layouts.GREY, 0) if k < n_walls else (layouts.LAVA, layouts.RED, 0)
+  return cells
+
+
+@pytest.mark.parametrize('W,H,A,V,n,max_steps', [(64, 64, 3, 5, 700, 60), (64, 64, 2, 7, 300, 60), (64, 37, 5, 5, 500, 50),
+                                                (3, 3, 1, 5, 200, 12), (4, 3, 1, 7, 200, 12), (3, 64, 1, 5, 200, 30), (5, 4, 3, 3, 200, 20)])
+def test_extreme_grid_sizes_parity(W, H, A, V, n, max_steps):
+  """The limits mg_create accepts (width / height in [3, 64]): coordinates fill their 6 bits, the padded map and the
+  distance LUT are at their largest in LDS (the view table no longer fits, so AUTO must fall back to the generic path),
+  and on the smallest grids the view is mostly the out-of-bounds ring."""
+  _need_gpu()
+  goal = (W - 2, H - 2) if W * H > 9 else None      # 3x3: the one interior cell is the agent's; no goal => the (13,13) fallback of v8:167
+  big = W * H > 1000
+  cells = _sprinkled(W, H, goal, 400 if big else 0, 40 if big else 0, seed=W * H + A)
+  env, orc = _make(cells, n, seed=W + H + A, n_agents=A, view_size=V, max_steps=max_steps)
+  if W == 64 and H == 64:
+    assert env.launch_info()['path'] == 'generic'
+  rng = np.random.RandomState(V)
+  env.reset()
+  orc.reset()
+  _cmp(env, orc, 'reset')
+  for t in range(2 * max_steps + 10):
+    act = rng.randint(0, 7, size=(A, orc.stride)).astype(np.uint8)
+    act[rng.rand(A, orc.stride) < 0.5] = 2
+    env.step(torch.from_numpy(act).to(env.device))
+    orc.step(act)
+    _cmp_step(env, orc, '%dx%d A%d V%d step %d' % (W, H, A, V, t))
+  assert env.check_errors() == 0
+  env.close()
+
+
+def test_longest_episode_step_counter_parity(cluttered_cells):
+  """max_steps at its limit (65534): the 16-bit step counter and the f64 goal reward late in a very long episode.
+  The handle is stepped 700 times, then its counters are pushed close to the limit through the state buffer on both
+  sides, and the last steps before the time-out are compared."""
+  _need_gpu()
+  n = 500
+  env, orc = _make(cluttered_cells, n, seed=65, max_steps=65534)
+  rng = np.random.RandomState(65)
+  env.reset()
+  orc.reset()
+
+  def steps(k, what):
+    for t in range(k):
+      act = rng.randint(0, 7, size=(3, orc.stride)).astype(np.uint8)
+      act[rng.rand(3, orc.stride) < 0.5] = 2
+      env.step(torch.from_numpy(act).to(env.device))
+      orc.step(act)
+      _cmp_step(env, orc, '%s step %d' % (what, t))
+
+  steps(60, 'early')
+  near = 65534 - 25
+  A = env.n_agents
+  torch.cuda.synchronize()
+  env.env_state[:, A] = (env.env_state[:, A] & ~0xFFFF) | near
+  for i in range(n):
+    orc.L.mgo_set_step_count(orc.envs[i], near)
+  _cmp(env, orc, 'after moving the counters')
+  steps(40, 'late')            # the 25th step times out and auto-resets; 15 steps of the next episode follow
+  assert int((env.step_count[:n] == 15).sum()) == n
+  assert env.check_errors() == 0
+  env.close()
