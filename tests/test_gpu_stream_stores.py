@@ -26,10 +26,14 @@ def _need_gpu():
     pytest.skip('no GPU')
 
 
-@pytest.mark.parametrize('path,n', [('table', 3000), ('generic', 3000), ('table', 70000)])
-def test_streamed_obs_shared_map_parity(cluttered_cells, monkeypatch, path, n):
+@pytest.mark.parametrize('path,n,grid', [('table', 3000, None), ('generic', 3000, None), ('table', 70000, None),
+                                         ('table', 20000, 3), ('generic', 20000, 2)])   # few workgroups: the rolling-prefetch loop
+def test_streamed_obs_shared_map_parity(cluttered_cells, monkeypatch, path, n, grid):
   _need_gpu()
   monkeypatch.setenv('MG_DEBUG_NT', '1')
+  if grid is not None:
+    monkeypatch.setenv('MG_DEBUG_GRID', str(grid))
+    monkeypatch.setenv('MG_DEBUG_NW', '4')
   from multigrid_amd.batched import BatchedMultiGrid
   env = BatchedMultiGrid(cluttered_cells, n_envs=n, seed=91, kernel_path=path)    # no env_reward => FAST
   orc = c_oracle.OracleBatch(cluttered_cells, n, shaping=1, auto_reset=1, seed=91)
