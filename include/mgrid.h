@@ -61,7 +61,8 @@ extern "C" {
  * persistent workgroups up to four chunks per resident wave (1,048,576 envs on 256 CUs), GENERIC launched one chunk per
  * wave beyond (in-order short-lived workgroups write faster once the working set exceeds the Infinity Cache).
  * Independently of the path, a launch beyond the resident batch (and a mutable-grid launch that writes 192 MiB of obs or
- * more) writes its obs images with non-temporal stores; the bytes are the same. */
+ * more) writes its obs images with non-temporal stores, a resident table launch of that size those of all agents but
+ * the last; the bytes are the same. */
 #define MG_PATH_AUTO    0
 #define MG_PATH_GENERIC 1
 #define MG_PATH_TABLE   2

@@ -669,7 +669,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       uint32_t s[NW + 1];
       uint64_t vm;
       dyn_view<V>(p, g, lut, pd_get(pd, a), (uint32_t)(carry >> (8 * a)) & 255u, s, vm);
-      emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB, p.nt_obs != 0);
+      emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB, ((p.nt_obs >> a) & 1) != 0);
     }
   }
 #endif

@@ -67,7 +67,7 @@ template <int V> struct ViewGeom {
 struct Params {
   int32_t W, H, max_steps, see_through, competitive, shaping, auto_reset, dd_bytes;
   int32_t op, random_actions, PW, PH, n_entries;
-  int32_t nt_obs;              // obs images leave with non-temporal stores (launch()'s streaming rule)
+  int32_t nt_obs;              // bit a: agent a's obs images leave with non-temporal stores (launch()'s streaming rule)
   int64_t n_envs, stride, n_chunks;
   uint64_t gid_base, t;
   uint32_t seed_lo, seed_hi;
@@ -723,7 +723,7 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
     uint64_t vm;
     if (TAB) table_view<V>(p, table, cidx, pd_get(pd, a), s, vm);
     else static_view<V>(p, map, pd_get(pd, a), s, vm);
-    emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB, p.nt_obs != 0);
+    emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB, ((p.nt_obs >> a) & 1) != 0);
   }
 #endif
 }
@@ -992,14 +992,17 @@ bool launch_uses_table(const mg_handle* h) {
 // launch_uses_table (1.3M envs 67.4 -> 61.8 us, 2M 114.3 -> 96.4, 4M 216.1 -> 192.3, 8M 427 -> 412; at 1M the resident
 // table kernel loses: 51.5 -> 57.7 us).  Mutable-grid kernels: from 192 MiB of obs per launch (DoorKey-8x8x3 at 1M envs
 // 167.3 -> 148.6 us, Meetup-15x15x3 307.4 -> 291.2; no difference either way below that).  tools/nt_sweep.sh, DESIGN §6.
-bool launch_streams_obs(const mg_handle* h) {
-  if (const char* e = debug_env("MG_DEBUG_NT")) return atoi(e) != 0;   // tuning experiments only
-  if (h->dynamic) {
-    const mg_config& c = h->cfg;
-    const int64_t per_env = h->full_obs ? (int64_t)c.width * c.height * 3 : (int64_t)c.n_agents * c.view_size * c.view_size * 3;
-    return h->stride * per_env >= ((int64_t)192 << 20);
-  }
-  return h->n_chunks > (int64_t)h->n_cu * 16 * kUpfront;
+// The launch-resident table kernel with 192 MiB of obs or more (the 1M-env bench shape: 236 MB) streams every agent's
+// images but the last one's: 50.4 us against 51.55 with none and 58.2 with all of them streamed, the same on three
+// runs (tools/nt_mask2.sh; streaming one agent's 50.8, another two 50.8 - 51.3).
+int launch_streams_obs(const mg_handle* h) {     // bit a = agent a's images
+  if (const char* e = debug_env("MG_DEBUG_NT")) return atoi(e);   // tests / tuning experiments only: the mask itself
+  const mg_config& c = h->cfg;
+  const int64_t per_env = h->full_obs ? (int64_t)c.width * c.height * 3 : (int64_t)c.n_agents * c.view_size * c.view_size * 3;
+  const bool big = h->stride * per_env >= ((int64_t)192 << 20);
+  if (h->dynamic) return big ? 0xFF : 0;
+  if (h->n_chunks > (int64_t)h->n_cu * 16 * kUpfront) return 0xFF;
+  return (big && launch_uses_table(h)) ? (1 << (c.n_agents - 1)) - 1 : 0;
 }
 
 void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid_out, size_t* lds_out) {
@@ -1081,7 +1084,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   p.gx = h->gx; p.gy = h->gy; p.LW = h->LW; p.LH = h->LH;
   p.fixed_mode = h->fixed_mode; p.fixed_pd = h->fixed_pd; p.fixed_pd_hi = h->fixed_pd_hi; p.reserved_pd = 0;
   p.scatter = reinterpret_cast<const uint16_t*>(scatter); p.aux = h->aux; p.obs_full = h->obs_full;
-  p.nt_obs = launch_streams_obs(h) ? 1 : 0;
+  p.nt_obs = launch_streams_obs(h);
   int nw; unsigned grid; size_t lds;
   DeviceGuard g(h->device);
   if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");

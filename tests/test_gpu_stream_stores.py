@@ -4,7 +4,7 @@ A launch that writes more obs than the Infinity Cache can usefully hold sends it
 The rule only fires on large batches (shared-map kernels beyond the launch-resident batch, mutable-grid kernels from
 192 MiB of obs per launch), whose parity the full-size tests cover through invariants and shard comparisons
 (test_gpu_parity.py::test_large_batch_takes_the_generic_kernels_one_chunk_per_wave, the 1M-env DoorKey invariants).
-Here MG_DEBUG_NT=1 forces the same store instructions onto batches small enough for the CPU oracle, so that every
+Here MG_DEBUG_NT=255 (a mask: bit a = agent a's images) forces the same store instructions onto batches small enough for the CPU oracle, so that every
 emitter (staged egocentric views on both shared-map paths and on the mutable-grid kernel, the fully observed gather)
 is compared bit for bit; MG_DEBUG_NT=0 pins the ordinary stores on a batch the rule would stream.
 """
@@ -26,11 +26,12 @@ def _need_gpu():
     pytest.skip('no GPU')
 
 
-@pytest.mark.parametrize('path,n,grid', [('table', 3000, None), ('generic', 3000, None), ('table', 70000, None),
-                                         ('table', 20000, 3), ('generic', 20000, 2)])   # few workgroups: the rolling-prefetch loop
-def test_streamed_obs_shared_map_parity(cluttered_cells, monkeypatch, path, n, grid):
+@pytest.mark.parametrize('path,n,grid,mask', [('table', 3000, None, 255), ('generic', 3000, None, 255), ('table', 70000, None, 255),
+                                              ('table', 20000, 3, 255), ('generic', 20000, 2, 255),   # few workgroups: the rolling-prefetch loop
+                                              ('table', 3000, None, 3), ('table', 20000, 3, 5)])      # some agents' images only (the 1M-env rule)
+def test_streamed_obs_shared_map_parity(cluttered_cells, monkeypatch, path, n, grid, mask):
   _need_gpu()
-  monkeypatch.setenv('MG_DEBUG_NT', '1')
+  monkeypatch.setenv('MG_DEBUG_NT', str(mask))
   if grid is not None:
     monkeypatch.setenv('MG_DEBUG_GRID', str(grid))
     monkeypatch.setenv('MG_DEBUG_NW', '4')
@@ -54,7 +55,7 @@ def test_streamed_obs_shared_map_parity(cluttered_cells, monkeypatch, path, n, g
 
 def test_streamed_obs_doorkey_parity(monkeypatch):
   _need_gpu()
-  monkeypatch.setenv('MG_DEBUG_NT', '1')
+  monkeypatch.setenv('MG_DEBUG_NT', '255')
   env, orc = test_gpu_dyn._doorkey(8, 3, 2000, 60, seed=83)
   env.reset()
   orc.reset()
@@ -72,7 +73,7 @@ def test_streamed_obs_doorkey_parity(monkeypatch):
 def test_streamed_obs_scatter_kinds_parity(monkeypatch, kind, size, A, goals, clutter):
   """Meetup's images are gathered straight from the LDS grids (emit_full); random Cluttered stages views like DoorKey."""
   _need_gpu()
-  monkeypatch.setenv('MG_DEBUG_NT', '1')
+  monkeypatch.setenv('MG_DEBUG_NT', '255')
   env, orc = test_gpu_scatter._make(kind, size, A, 1200, 45, seed=size + A, V=5, n_goals=goals, n_clutter=clutter)
   env.reset()
   orc.reset()
@@ -86,12 +87,13 @@ def test_streamed_obs_scatter_kinds_parity(monkeypatch, kind, size, A, goals, cl
   env.close()
 
 
-def test_streamed_and_ordinary_stores_agree_at_full_size(cluttered_cells, monkeypatch):
-  """1,310,720 envs (beyond the launch-resident batch, so the rule streams): the same handle configuration run with the
-  rule's choice and with ordinary stores forced gives identical buffers."""
+@pytest.mark.parametrize('n', [1_310_720, 1_048_576])
+def test_streamed_and_ordinary_stores_agree_at_full_size(cluttered_cells, monkeypatch, n):
+  """1,310,720 envs (beyond the launch-resident batch: the rule streams every image) and the 1,048,576-env bench shape (the
+  resident table kernel streams all agents' images but the last one's): the same handle configuration run with the rule's
+  choice and with ordinary stores forced gives identical buffers."""
   _need_gpu()
   from multigrid_amd.batched import BatchedMultiGrid
-  n = 1_310_720
   a = BatchedMultiGrid(cluttered_cells, n_envs=n, seed=17)
   b = BatchedMultiGrid(cluttered_cells, n_envs=n, seed=17)
   g = torch.Generator(device=a.device)
