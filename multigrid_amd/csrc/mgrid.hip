@@ -780,17 +780,29 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
     // (named variables, not an array: whether a loop over an array unrolls depends on the size of do_chunk, and an
     // array indexed at run time lives in scratch, where it would be stored while its loads are still in flight)
     static_assert(kUpfront == 4, "four explicit slots below");
-    const bool h1 = c + 1 * cstride < p.n_chunks, h2 = c + 2 * cstride < p.n_chunks, h3 = c + 3 * cstride < p.n_chunks;
+    // Chunk of this wave in window k (a window = one chunk for every wave of the launch).  A batch that is not a whole
+    // number of windows ends in a partial one; dealt out like the others it would leave the workgroups at the end of the
+    // grid idle for that window (917,504 envs = 3.5 windows: half the CUs stop after three chunks).  The partial window
+    // is therefore dealt out transposed — consecutive chunks to consecutive workgroups — so that every CU gets its share.
+    const int64_t c0 = c;
+    auto chunk_of = [&](int k) -> int64_t {
+      const int64_t base = (int64_t)k * cstride;
+      const bool partial = k > 0 && base + cstride > p.n_chunks;
+      const int64_t ck = base + (partial ? (int64_t)wv * gridDim.x + blockIdx.x : c0);
+      return ck < p.n_chunks ? ck : (int64_t)-1;
+    };
+    const int64_t c1 = chunk_of(1), c2 = chunk_of(2), c3 = chunk_of(3);
+    const bool h1 = c1 >= 0, h2 = c2 >= 0, h3 = c3 >= 0;
     ChunkIn in1, in2, in3;
     zero_chunk(in1); zero_chunk(in2); zero_chunk(in3);
-    if (h1) load_chunk<A, FAST>(p, (c + 1 * cstride) * kWave, lane, in1);
-    if (h2) load_chunk<A, FAST>(p, (c + 2 * cstride) * kWave, lane, in2);
-    if (h3) load_chunk<A, FAST>(p, (c + 3 * cstride) * kWave, lane, in3);
+    if (h1) load_chunk<A, FAST>(p, c1 * kWave, lane, in1);
+    if (h2) load_chunk<A, FAST>(p, c2 * kWave, lane, in2);
+    if (h3) load_chunk<A, FAST>(p, c3 * kWave, lane, in3);
     wait_chunk<0>(cur); wait_chunk<0>(in1); wait_chunk<0>(in2); wait_chunk<0>(in3);
     if (c < p.n_chunks) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, c * kWave, cur, err);
-    if (h1) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, (c + 1 * cstride) * kWave, in1, err);
-    if (h2) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, (c + 2 * cstride) * kWave, in2, err);
-    if (h3) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, (c + 3 * cstride) * kWave, in3, err);
+    if (h1) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, c1 * kWave, in1, err);
+    if (h2) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, c2 * kWave, in2, err);
+    if (h3) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, c3 * kWave, in3, err);
   } else {
     if (c < p.n_chunks) wait_chunk<0>(cur);
     for (; c < p.n_chunks; c += cstride) {

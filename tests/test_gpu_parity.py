@@ -746,3 +746,27 @@ def test_longest_episode_step_counter_parity(cluttered_cells):
   assert int((env.step_count[:n] == 15).sum()) == n
   assert env.check_errors() == 0
   env.close()
+
+
+@pytest.mark.parametrize('n', [64 * 30, 64 * 13 + 5, 64 * 47])
+def test_resident_batch_with_a_partial_last_window(cluttered_cells, monkeypatch, n):
+  """Launch-resident path (all inputs fetched up front) on a batch that is not a whole number of windows: with 3 workgroups
+  of 4 waves a window is 12 chunks, so 30 chunks = 2.5 windows, 14 = 1 + 2 chunks, 47 = 4 windows less one chunk.  The
+  partial window is dealt out transposed over the workgroups; every chunk must still be stepped exactly once."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  monkeypatch.setenv('MG_DEBUG_GRID', '3')
+  monkeypatch.setenv('MG_DEBUG_NW', '4')
+  env = BatchedMultiGrid(cluttered_cells, n_envs=n, seed=707, kernel_path='table')    # no env_reward => FAST
+  orc = c_oracle.OracleBatch(cluttered_cells, n, shaping=1, auto_reset=1, seed=707)
+  rng = np.random.RandomState(707)
+  env.reset()
+  orc.reset()
+  for t in range(40):
+    act = rng.randint(0, 7, size=(3, orc.stride)).astype(np.uint8)
+    act[rng.rand(3, orc.stride) < 0.35] = 2
+    env.step(torch.from_numpy(act).to(env.device))
+    orc.step(act)
+    _cmp_step(env, orc, 'partial window n=%d step %d' % (n, t))
+  assert env.check_errors() == 0
+  env.close()
