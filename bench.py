@@ -66,14 +66,50 @@ def cpu_baseline(cells, seconds=12.0):
   return out
 
 
+TRAFFIC_FILES = ('r2_traffic.json', 'r1_traffic.json')   # newest first
+
+
+def kernel_source_hash():
+  """Hash of the kernel sources the loaded library was built from: stamps a PMC traffic figure with the build it was
+  measured on, so that a stale profiles/*_traffic.json is visible in the bench line."""
+  import hashlib
+  h = hashlib.sha256()
+  for f in ('mgrid.hip', 'mg_dyn.h', 'mg_vis.h'):
+    with open(os.path.join(ROOT, 'multigrid_amd', 'csrc', f), 'rb') as fh:
+      h.update(fh.read())
+  return h.hexdigest()[:12]
+
+
 def measured_traffic(envs):
-  """HBM bytes per launch from the committed PMC passes (profiles/r1_traffic.json), when they were
-  taken at this batch size; None otherwise (counters cannot be read from inside the bench)."""
-  try:
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')))
-    return d['hbm_bytes_per_launch'] if d['envs_per_gpu'] == envs else None
-  except Exception:
-    return None
+  """(HBM bytes per launch, provenance) from the committed PMC passes, when they were taken at this batch size;
+  (None, None) otherwise — counters cannot be read from inside the bench.  The provenance says which build the
+  passes ran on and whether that is the build being timed now."""
+  for name in TRAFFIC_FILES:
+    try:
+      d = json.load(open(os.path.join(ROOT, 'profiles', name)))
+    except Exception:
+      continue
+    if d.get('envs_per_gpu') != envs:
+      continue
+    src = d.get('source_hash')
+    return d['hbm_bytes_per_launch'], {'file': 'profiles/' + name, 'build': d.get('build'), 'source_hash': src,
+                                       'current_source_hash': kernel_source_hash(),
+                                       'stale': src != kernel_source_hash()}
+  return None, None
+
+
+def spawn_ranks(n):
+  """`python bench.py --gpus N` without a launcher around it: start N fresh ranks (one per GPU) under
+  torch.distributed.run and hand their single JSON line through.  Runs before this process has made any GPU call
+  (nothing but argparse has happened), and as a child process, never an exec."""
+  import socket
+  import subprocess
+  with socket.socket() as sock:
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.call(cmd)
 
 
 def main():
@@ -88,7 +124,22 @@ def main():
   ap.add_argument('--cpu-seconds', type=float, default=12.0)
   ap.add_argument('--env-id', default=ENV_ID, help='any registered id; anything but the default is a side measurement '
                   '(mutable-grid kernel: DoorKey / Meetup / random Cluttered), not the BASELINE metric')
+  ap.add_argument('--also-envs', type=int, default=131072, help='second, short measurement at this many envs per GPU '
+                  "(BASELINE config 3's literal per-GPU shard at 8 GPUs), reported under 'also'; 0 = off")
+  ap.add_argument('--no-stagger', action='store_true', help='leave every env at episode age 0 after reset (all envs '
+                  'then auto-reset in the same launch, once per max_steps steps)')
+  ap.add_argument('--rehearse-cpu', action='store_true', help='launcher rehearsal without a GPU: ranks rendezvous (gloo), '
+                  'time a sleep instead of the kernel and print the same JSON shape; tests/test_bench_launcher.py')
   args = ap.parse_args()
+
+  if args.gpus < 1:
+    sys.exit('--gpus must be >= 1')
+  if 'RANK' not in os.environ and args.gpus > 1:
+    sys.exit(spawn_ranks(args.gpus))
+  if int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
+    sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks' % (args.gpus, os.environ.get('WORLD_SIZE', '1')))
+  if args.rehearse_cpu:
+    return rehearse_cpu(args)
 
   # stdout carries exactly one line, the JSON: library banners (RCCL prints its version block to stdout when the
   # first communicator is created, gloo its peer count) are sent to stderr by pointing fd 1 there until the end
@@ -117,25 +168,7 @@ def main():
     torch.cuda.set_device(0)
     local_rank = 0
   dev = torch.device('cuda', local_rank)
-
-  base, n = shard.shard_range(rank, world, args.envs)
-  env = multigrid_amd.make_batched(args.env_id, n, device=local_rank, seed=0xC0FFEE, env_id_base=base,
-                                   shaping='v8', auto_reset=True)
   headline = args.env_id == ENV_ID
-  A, V = env.n_agents, env.view_size
-  # bytes one env-step has to move: obs + dir/done + f64 rewards + actions + env_state r/w,
-  # and for per-env grids: carry r/w + grid rows r/w (+ aux r/w)
-  b_alg = B_ALG_PER_ENV_STEP if headline else (
-      (env.width * env.height * 3 if env.obs_full is not None else A * V * V * 3) + (4 if A < 4 else 8) + 8 * A + env.slots +
-      8 * (A + 1) + ((2 * env.slots + 8 * env.grid_words) if env.mutable_grid else 0) + (32 if env.aux is not None else 0))
-  gen = torch.Generator(device=dev)
-  gen.manual_seed(1234 + rank)
-  ring = torch.randint(0, 7, (ACTION_RING, env.stride, env.slots), dtype=torch.uint8, device=dev, generator=gen)
-  env.reset()
-
-  def run(k):
-    for i in range(k):
-      env.step(ring[i % ACTION_RING])
 
   def barrier():
     torch.cuda.synchronize(dev)
@@ -143,47 +176,134 @@ def main():
       dist.barrier()
     torch.cuda.synchronize(dev)
 
-  run(args.warmup)
-  barrier()
-  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  t0 = time.perf_counter()
-  ev0.record()
-  run(args.steps)
-  ev1.record()
-  torch.cuda.synchronize(dev)
-  wall = time.perf_counter() - t0
-  if dist is not None:
-    dist.barrier()
-  kernel_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream
-  wall, value = shard.aggregate(dist, wall, float(n) * env.n_agents * args.steps, world)   # max over ranks
-  kernel_ms, _ = shard.aggregate(dist, kernel_ms, 0.0, world)
-  errs = env.check_errors()
+  def measure(envs_per_gpu, warmup, steps):
+    """W untimed + exactly K timed steps of `envs_per_gpu` envs on this rank; whole-job numbers (max over ranks)."""
+    base, n = shard.shard_range(rank, world, envs_per_gpu)
+    env = multigrid_amd.make_batched(args.env_id, n, device=local_rank, seed=0xC0FFEE, env_id_base=base,
+                                     shaping='v8', auto_reset=True)
+    A, V = env.n_agents, env.view_size
+    # bytes one env-step has to move (SURVEY §8d): obs + dir/done + f64 rewards + actions + env_state r/w,
+    # and for per-env grids: carry r/w + grid rows r/w (+ aux r/w)
+    b_alg = B_ALG_PER_ENV_STEP if headline else (
+        (env.width * env.height * 3 if env.obs_full is not None else A * V * V * 3) + (4 if A < 4 else 8) + 8 * A + env.slots +
+        8 * (A + 1) + ((2 * env.slots + 8 * env.grid_words) if env.mutable_grid else 0) + (32 if env.aux is not None else 0))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    ring = torch.randint(0, 7, (ACTION_RING, env.stride, env.slots), dtype=torch.uint8, device=dev, generator=gen)
+    env.reset()
+    # Auto-resets inside the timed region.  Every env of this id times out after max_steps steps, so a batch reset
+    # together resets together: 99 cheap launches, then one in which every env respawns — and a short timed region
+    # (the driver's 20 steps) would contain none.  The 64-env chunks therefore start at staggered episode ages
+    # (chunk c at step_count c mod max_steps, written through the public env_state layout, include/mgrid.h): every
+    # launch then auto-resets 1/max_steps of the envs, whole wavefronts at a time, and costs the long-run average.
+    reset_frac = None
+    if not args.no_stagger and not env.mutable_grid:
+      ms = env.max_steps
+      phase = (torch.arange(env.stride, device=dev, dtype=torch.int32) // 64) % ms
+      env._env_state[:, A] = phase
+      idx = torch.arange(warmup, warmup + steps, device=dev, dtype=torch.int64)
+      hits = ((phase[:n].to(torch.int64)[None, :] + idx[:, None] + 1) % ms == 0) if n * steps <= (1 << 24) else None
+      reset_frac = float(hits.float().mean()) if hits is not None else 1.0 / ms
+
+    def run(k):
+      for i in range(k):
+        env.step(ring[i % ACTION_RING])
+
+    run(warmup)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(steps)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    if dist is not None:
+      dist.barrier()
+    kernel_ms = ev0.elapsed_time(ev1) / steps      # HIP events on the launch stream
+    wall, value = shard.aggregate(dist, wall, float(n) * A * steps, world)   # max over ranks
+    kernel_ms, _ = shard.aggregate(dist, kernel_ms, 0.0, world)
+    res = {'n': n, 'A': A, 'V': V, 'b_alg': b_alg, 'wall': wall, 'value': value, 'kernel_ms': kernel_ms,
+           'errs': env.check_errors(), 'launch': env.launch_info(), 'mutable': env.mutable_grid, 'cells': env.cells,
+           'reset_frac': reset_frac}
+    env.close()
+    return res
+
+  m = measure(args.envs, args.warmup, args.steps)
+  also = None
+  if headline and args.also_envs and args.also_envs != args.envs:
+    also = measure(args.also_envs, min(args.warmup, 100), min(args.steps, 500))
 
   if rank == 0:
-    achieved = b_alg * n / (kernel_ms * 1e-3) / 1e9
+    n, A, V = m['n'], m['A'], m['V']
+    achieved = m['b_alg'] * n / (m['kernel_ms'] * 1e-3) / 1e9
+    traffic, traffic_from = measured_traffic(n) if headline else (None, None)
     out = {
         'metric': 'env agent-steps/sec (whole node) Cluttered-15x15 3 agents; % HBM roofline' if headline else
                   'env agent-steps/sec, side measurement on %s (not the BASELINE metric)' % args.env_id,
-        'value': value, 'unit': 'agent-steps/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True,
+        'value': m['value'], 'unit': 'agent-steps/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': m['wall'] / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8 obs/state + f64 rewards', 'data': 'synthetic',
         'config': {'workload': '%s, %d agents, view %d, v8 shaping + auto-reset fused, %d envs per GPU, '
                                'uniform random actions resident in HBM' % (args.env_id, A, V, n),
-                   'envs_per_gpu': n, 'global_envs': n * world, 'parallelism': 'env-sharded x%d, no collective in step' % world},
+                   'envs_per_gpu': n, 'global_envs': n * world, 'parallelism': 'env-sharded x%d, no collective in step' % world,
+                   'auto_reset': {'episode_ages': 'all zero (every env resets in the same launch)' if m['reset_frac'] is None else
+                                  'staggered by 64-env chunk (chunk c starts at step_count c mod max_steps)',
+                                  'env_steps_reset_in_timed_region_frac': m['reset_frac']}},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(n) if headline else None,
-                     'kernel': ('mg_dyn_kernel<%d,%d>' % (A, V)) if env.mutable_grid else
-                               ('mg_kernel<%d,%d,%s,fast>' % (A, V, env.launch_info()['path'])),
-                     'kernel_ms': kernel_ms, 'launch': env.launch_info(), 'alg_bytes_per_launch': b_alg * n},
-        'device_errors': errs,
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_from': traffic_from,
+                     'kernel': ('mg_dyn_kernel<%d,%d>' % (A, V)) if m['mutable'] else
+                               ('mg_kernel<%d,%d,%s,fast>' % (A, V, m['launch']['path'])),
+                     'kernel_ms': m['kernel_ms'], 'launch': m['launch'], 'alg_bytes_per_launch': m['b_alg'] * n},
+        'device_errors': m['errs'],
     }
+    if also is not None:
+      a_ach = also['b_alg'] * also['n'] / (also['kernel_ms'] * 1e-3) / 1e9
+      out['also'] = {'workload': "same env, %d envs per GPU (BASELINE config 3's per-GPU shard of 1M envs over 8 GPUs)" % also['n'],
+                     'value': also['value'], 'unit': 'agent-steps/s', 'kernel_ms': also['kernel_ms'],
+                     'roofline_frac': a_ach / HBM_PEAK_GBS, 'launch': also['launch'], 'device_errors': also['errs']}
     if world == 1 and not args.no_cpu_baseline and headline:
-      out['cpu_baseline'] = cpu_baseline(env.cells, args.cpu_seconds)
+      out['cpu_baseline'] = cpu_baseline(m['cells'], args.cpu_seconds)
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     print(json.dumps(out), flush=True)
     os.dup2(2, 1)
-  env.close()
+  if dist is not None:
+    dist.destroy_process_group()
+
+
+def rehearse_cpu(args):
+  """The N-rank plumbing of this file without a GPU (gloo): rendezvous, barrier, max-over-ranks timing, one JSON line
+  from rank 0.  The timed "step" is a sleep; nothing here is a measurement."""
+  sys.stdout.flush()
+  real_stdout = os.dup(1)
+  os.dup2(2, 1)                      # gloo's banner goes to stderr, as RCCL's does in main()
+  import torch.distributed as dist
+  from multigrid_amd import shard
+  world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+  if 'RANK' in os.environ:
+    dist.init_process_group('gloo')
+  else:
+    dist = None
+  base, n = shard.shard_range(rank, world, args.envs)
+  if dist is not None:
+    dist.barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    time.sleep(0.001 * (1 + rank))
+  wall = time.perf_counter() - t0
+  if dist is not None:
+    dist.barrier()
+  wall, value = shard.aggregate(dist, wall, float(n) * 3 * args.steps, world)
+  if rank == 0:
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps({'rehearsal': True, 'metric': 'launcher rehearsal (sleep), not a measurement', 'value': value,
+                      'unit': 'agent-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                      'ms_per_step': wall / args.steps * 1e3,
+                      'config': {'envs_per_gpu': n, 'global_envs': n * world, 'env_id_base_of_last_rank': (world - 1) * n}}),
+          flush=True)
+    os.dup2(2, 1)
   if dist is not None:
     dist.destroy_process_group()
 

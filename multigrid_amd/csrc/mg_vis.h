@@ -19,11 +19,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
-#define MG_HD __host__ __device__ __forceinline__
-#else
-#define MG_HD inline
-#endif
+#define MG_HD __host__ __device__ __forceinline__   // only ever compiled by hipcc (mgrid.hip)
 
 // opq[j] = opacity bits of row j (bit i set <=> cell (i,j) is opaque).  vis[j] out.
 template <int V>

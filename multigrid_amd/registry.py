@@ -124,6 +124,11 @@ def make_batched(env_id, n_envs, **kw):
 
 
 def make(env_id, **kw):
-  """gym.make(env_id) counterpart: one env with the reference's list-of-arrays contract."""
+  """gym.make(env_id) counterpart: one env with the reference's list-of-arrays contract — and the reference env's
+  behaviour by default: unshaped env rewards (multigrid.py:881-883; the v8 controller shapes them itself,
+  v8_robust_ppo.py:171-220, and would read a pre-shaped +0.02 as a goal touch) and no auto-reset (the obs of a done
+  step is the terminal obs, the caller resets: multigrid.py:963-995).  make_batched keeps the fused defaults."""
   from .compat import RefCompatEnv
+  kw.setdefault('shaping', None)
+  kw.setdefault('auto_reset', False)
   return RefCompatEnv(make_batched(env_id, 1, **kw), minigrid_mode=spec(env_id).get('minigrid_mode', False))

@@ -1,0 +1,58 @@
+"""`python bench.py --gpus N` must itself start N ranks (round-1 finding: the flag was parsed and ignored).
+
+CPU: the launcher + rendezvous + max-over-ranks aggregation + single JSON line, with a sleep standing in for the
+kernel (`--rehearse-cpu`).  GPU (one card): the real bench with two gloo ranks that share cuda:0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, env=None, timeout=600):
+  e = dict(os.environ)
+  for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+    e.pop(k, None)
+  e.update(env or {})
+  return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, capture_output=True, text=True,
+                        env=e, timeout=timeout, cwd=ROOT)
+
+
+def _one_json_line(stdout):
+  lines = [l for l in stdout.splitlines() if l.strip()]
+  assert len(lines) == 1, stdout
+  return json.loads(lines[0])
+
+
+def test_gpus_flag_alone_starts_the_ranks():
+  r = _run(['--gpus', '2', '--rehearse-cpu', '--steps', '4', '--envs', '1000'])
+  assert r.returncode == 0, r.stderr[-2000:]
+  d = _one_json_line(r.stdout)
+  assert d['n_gpus'] == 2 and d['config']['global_envs'] == 2000 and d['config']['env_id_base_of_last_rank'] == 1000
+  # max over ranks: rank 1 sleeps 2 ms per step
+  assert d['ms_per_step'] >= 2.0
+
+
+def test_world_size_that_disagrees_with_the_flag_is_an_error():
+  r = _run(['--gpus', '3', '--rehearse-cpu'], env={'RANK': '0', 'WORLD_SIZE': '2'})
+  assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr
+
+
+def test_single_rank_needs_no_launcher():
+  r = _run(['--rehearse-cpu', '--steps', '2'])
+  assert r.returncode == 0, r.stderr[-2000:]
+  assert _one_json_line(r.stdout)['n_gpus'] == 1
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_card_real_bench():
+  r = _run(['--gpus', '2', '--backend', 'gloo', '--all-on-device0', '--envs', '8192', '--also-envs', '0', '--steps', '30',
+            '--warmup', '5', '--no-cpu-baseline'])
+  assert r.returncode == 0, r.stderr[-3000:]
+  d = _one_json_line(r.stdout)
+  assert d['n_gpus'] == 2 and d['config']['envs_per_gpu'] == 8192 and d['config']['global_envs'] == 16384
+  assert d['device_errors'] == 0 and d['value'] > 0
+  assert 0.0 < d['config']['auto_reset']['env_steps_reset_in_timed_region_frac'] < 0.05

@@ -440,6 +440,25 @@ def test_refcompat_env_contract():
   env.close()
 
 
+def test_default_make_is_the_unshaped_reference_env():
+  """make(env_id) with no kwargs is gym.make's env: rewards are the env rewards (multigrid.py:881-883; 0 or 1 - 0.9 s/max_steps,
+  never a shaped +0.02 that v8's controller would take for a goal touch, v8_robust_ppo.py:181) and the done step returns the
+  terminal obs — no auto-reset (multigrid.py:963-995)."""
+  _need_gpu()
+  import multigrid_amd
+  env = multigrid_amd.make('MultiGrid-Cluttered-Fixed-15x15', max_steps=6, emit_env_reward=True, seed=4)
+  assert env.b.cfg.shaping_kind == 0 and env.b.cfg.auto_reset == 0
+  env.reset()
+  for s in range(1, 7):
+    obs, rew, done, _ = env.step([2, 0, 2])
+    assert np.array_equal(env.b.reward.cpu().numpy().view(np.int64), env.b.env_reward.cpu().numpy().view(np.int64))
+    assert all(r == 0 or r == 1 - 0.9 * (s / 6) for r in rew)
+    assert done == (s == 6)
+  assert env.step_count == 6                       # not reset behind the caller's back
+  assert obs['direction'] == env.agent_dir         # the obs returned with done is the terminal state's
+  env.close()
+
+
 def test_golden_replay_fixture():
   """tests/golden/replay_cluttered_fixed_15x15.npz (recorded from the Python restatement driven
   with NumPy's PCG64 / MT19937 streams like the reference) replayed through the C ABI: all 24
