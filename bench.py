@@ -126,8 +126,8 @@ def main():
                   '(mutable-grid kernel: DoorKey / Meetup / random Cluttered), not the BASELINE metric')
   ap.add_argument('--also-envs', type=int, default=131072, help='second, short measurement at this many envs per GPU '
                   "(BASELINE config 3's literal per-GPU shard at 8 GPUs), reported under 'also'; 0 = off")
-  ap.add_argument('--no-stagger', action='store_true', help='leave every env at episode age 0 after reset (all envs '
-                  'then auto-reset in the same launch, once per max_steps steps)')
+  ap.add_argument('--stagger', action='store_true', help='start the 64-env chunks at staggered episode ages, so that every launch '
+                  'auto-resets 1/max_steps of the envs (default: lock-step, all envs auto-reset in the same launch)')
   ap.add_argument('--rehearse-cpu', action='store_true', help='launcher rehearsal without a GPU: ranks rendezvous (gloo), '
                   'time a sleep instead of the kernel and print the same JSON shape; tests/test_bench_launcher.py')
   args = ap.parse_args()
@@ -176,7 +176,7 @@ def main():
       dist.barrier()
     torch.cuda.synchronize(dev)
 
-  def measure(envs_per_gpu, warmup, steps):
+  def measure(envs_per_gpu, warmup, steps, long_cycle=False):
     """W untimed + exactly K timed steps of `envs_per_gpu` envs on this rank; whole-job numbers (max over ranks)."""
     base, n = shard.shard_range(rank, world, envs_per_gpu)
     env = multigrid_amd.make_batched(args.env_id, n, device=local_rank, seed=0xC0FFEE, env_id_base=base,
@@ -191,19 +191,20 @@ def main():
     gen.manual_seed(1234 + rank)
     ring = torch.randint(0, 7, (ACTION_RING, env.stride, env.slots), dtype=torch.uint8, device=dev, generator=gen)
     env.reset()
-    # Auto-resets inside the timed region.  Every env of this id times out after max_steps steps, so a batch reset
-    # together resets together: 99 cheap launches, then one in which every env respawns — and a short timed region
-    # (the driver's 20 steps) would contain none.  The 64-env chunks therefore start at staggered episode ages
-    # (chunk c at step_count c mod max_steps, written through the public env_state layout, include/mgrid.h): every
-    # launch then auto-resets 1/max_steps of the envs, whole wavefronts at a time, and costs the long-run average.
-    reset_frac = None
-    if not args.no_stagger and not env.mutable_grid:
-      ms = env.max_steps
+    # Auto-resets inside the timed region.  Every env of this id times out after max_steps steps (done = step_count >=
+    # max_steps only, multigrid.py:986-993 with three agents), so a batch that was reset together auto-resets together,
+    # as the reference's envs would: max_steps - 1 plain launches, then one in which every env respawns.  The bench
+    # line says how many of those launches the timed region held, and `long_run` (below) times one whole episode
+    # cycle so that a short timed region (the driver's 20 steps hold none) can be compared with the long-run rate.
+    # --stagger starts the 64-env chunks at episode ages c mod max_steps instead (written through the public env_state
+    # layout, include/mgrid.h): every launch then auto-resets 1/max_steps of the envs, whole wavefronts at a time.
+    ms = env.max_steps
+    reset_launches = sum(1 for i in range(warmup, warmup + steps) if (i + 1) % ms == 0)
+    reset_frac = reset_launches / float(steps)
+    if args.stagger and not env.mutable_grid:
       phase = (torch.arange(env.stride, device=dev, dtype=torch.int32) // 64) % ms
       env._env_state[:, A] = phase
-      idx = torch.arange(warmup, warmup + steps, device=dev, dtype=torch.int64)
-      hits = ((phase[:n].to(torch.int64)[None, :] + idx[:, None] + 1) % ms == 0) if n * steps <= (1 << 24) else None
-      reset_frac = float(hits.float().mean()) if hits is not None else 1.0 / ms
+      reset_launches, reset_frac = None, 1.0 / ms
 
     def run(k):
       for i in range(k):
@@ -223,13 +224,37 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / steps      # HIP events on the launch stream
     wall, value = shard.aggregate(dist, wall, float(n) * A * steps, world)   # max over ranks
     kernel_ms, _ = shard.aggregate(dist, kernel_ms, 0.0, world)
+    long_run = None
+    if long_cycle and not args.stagger and not env.mutable_grid and ms <= 1000:
+      # one whole episode cycle, timed in two parts: the max_steps - 1 plain launches and the one all-reset launch
+      done = warmup + steps
+      run((ms - done % ms) % ms)                 # to the start of a cycle (every env at step_count 0)
+      evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+      plain, reset = [], []
+      for _ in range(3):
+        torch.cuda.synchronize(dev)
+        evs[0].record()
+        run(ms - 1)
+        evs[1].record()
+        run(1)
+        evs[2].record()
+        torch.cuda.synchronize(dev)
+        plain.append(evs[0].elapsed_time(evs[1]) / (ms - 1))
+        reset.append(evs[1].elapsed_time(evs[2]))
+      p_ms, r_ms = sorted(plain)[1], sorted(reset)[1]
+      p_ms, _ = shard.aggregate(dist, p_ms, 0.0, world)
+      r_ms, _ = shard.aggregate(dist, r_ms, 0.0, world)
+      cyc = ((ms - 1) * p_ms + r_ms) / ms
+      long_run = {'plain_launch_ms': p_ms, 'all_reset_launch_ms': r_ms, 'kernel_ms_per_step': cyc,
+                  'value': float(n) * A * world / (cyc * 1e-3), 'roofline_frac': b_alg * n / (cyc * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  'note': 'median of 3 episode cycles of %d launches, HIP events; kernel time only' % ms}
     res = {'n': n, 'A': A, 'V': V, 'b_alg': b_alg, 'wall': wall, 'value': value, 'kernel_ms': kernel_ms,
            'errs': env.check_errors(), 'launch': env.launch_info(), 'mutable': env.mutable_grid, 'cells': env.cells,
-           'reset_frac': reset_frac}
+           'reset_frac': reset_frac, 'reset_launches': reset_launches, 'long_run': long_run}
     env.close()
     return res
 
-  m = measure(args.envs, args.warmup, args.steps)
+  m = measure(args.envs, args.warmup, args.steps, long_cycle=True)
   also = None
   if headline and args.also_envs and args.also_envs != args.envs:
     also = measure(args.also_envs, min(args.warmup, 100), min(args.steps, 500))
@@ -247,9 +272,11 @@ def main():
         'config': {'workload': '%s, %d agents, view %d, v8 shaping + auto-reset fused, %d envs per GPU, '
                                'uniform random actions resident in HBM' % (args.env_id, A, V, n),
                    'envs_per_gpu': n, 'global_envs': n * world, 'parallelism': 'env-sharded x%d, no collective in step' % world,
-                   'auto_reset': {'episode_ages': 'all zero (every env resets in the same launch)' if m['reset_frac'] is None else
-                                  'staggered by 64-env chunk (chunk c starts at step_count c mod max_steps)',
-                                  'env_steps_reset_in_timed_region_frac': m['reset_frac']}},
+                   'auto_reset': {'episode_ages': 'staggered by 64-env chunk (chunk c starts at step_count c mod max_steps)' if args.stagger
+                                  else 'in lock-step (every env times out in the same launch, once per max_steps launches)',
+                                  'all_reset_launches_in_timed_region': m['reset_launches'],
+                                  'env_steps_reset_in_timed_region_frac': m['reset_frac'],
+                                  'long_run': m['long_run']}},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_from': traffic_from,
                      'kernel': ('mg_dyn_kernel<%d,%d>' % (A, V)) if m['mutable'] else

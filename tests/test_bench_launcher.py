@@ -50,7 +50,7 @@ def test_single_rank_needs_no_launcher():
 @pytest.mark.gpu
 def test_two_ranks_on_one_card_real_bench():
   r = _run(['--gpus', '2', '--backend', 'gloo', '--all-on-device0', '--envs', '8192', '--also-envs', '0', '--steps', '30',
-            '--warmup', '5', '--no-cpu-baseline'])
+            '--warmup', '5', '--no-cpu-baseline', '--stagger'])
   assert r.returncode == 0, r.stderr[-3000:]
   d = _one_json_line(r.stdout)
   assert d['n_gpus'] == 2 and d['config']['envs_per_gpu'] == 8192 and d['config']['global_envs'] == 16384
