@@ -122,6 +122,8 @@ extern "C" {
 #define MG_ERR_BAD_RESPAWN  2u  /* injected respawn/spawn/object cell occupied or out of range, or bad injected layout draw */
 #define MG_ERR_BAD_ORDER    4u  /* injected order is not a permutation */
 #define MG_ERR_MISSING_DRAW 8u  /* replay step needed a respawn/spawn that was not injected */
+#define MG_ERR_BAD_MAP     16u  /* mg_step_noalloc: the layout holds a cell type shared static maps cannot hold, or fewer free
+                                   cells than agents (mg_set_static_map refuses both on the host; a device layout cannot be) */
 
 /* Mirrors the ctor kwargs of MultiGridEnv (multigrid.py:325-339) + ClutteredMultiGrid
  * (cluttered.py:16-23), plus batching/sharding fields that have no reference counterpart. */
@@ -274,6 +276,32 @@ int mg_export_grid(mg_handle* h, uint8_t* out);
  * `actions_out` (device uint8[env_stride][MG_SLOTS(n_agents)], same layout as `actions`; may be NULL). */
 int mg_step_random(mg_handle* h, uint8_t* actions_out);
 
+/* mg_step for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE (cxh42/multigrid is pure Python): it exists
+ * for callers that must not reach hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation.  One free-running env.step(actions) (multigrid.py:963-995 + v8 shaping + auto-reset, as mg_step) of cfg->n_envs
+ * envs on a shared static layout, with NO handle: every buffer is the caller's, and what a handle keeps in hipMalloc'ed
+ * tables (padded map, goal-distance table, error word) lives in a 64 KB file-scope __device__ array of the library, one copy
+ * per GPU, held until the process ends.  The call itself allocates and frees nothing and does not synchronise: it enqueues
+ * one 4-byte memset, a one-workgroup kernel that rebuilds the tables from `cells`, the step kernel and (err_out != NULL) one
+ * 4-byte device-to-device copy on `hip_stream`.  The array's device address is looked up once per device
+ * (hipGetSymbolAddress), by the first mg_create on that device or else by the first call of this function there.
+ *   cfg        as for mg_create; env_kind must be MG_KIND_STATIC, emit_env_reward 0; kernel_path is ignored (the generic
+ *              kernel, one chunk per wave); seed / env_id_base key the Philox draws exactly as in mg_step
+ *   step_index the Philox step index of this step (what mg_get_step_index reports for a handle)
+ *   cells      DEVICE uint8[H*W*3], the layout mg_set_static_map takes from the host: empty / wall / goal / lava cells only
+ *              (anything else is treated as a wall and reported as MG_ERR_BAD_MAP)
+ *   actions    device uint8[env_stride][MG_SLOTS(A)]                       (in)
+ *   env_state  device uint32[env_stride][A+1], layout of mg_buffers        (in/out)
+ *   obs_image  device uint8[A][env_stride][V*V*3]; reward device double[A][env_stride]; dir_done device
+ *              uint8[env_stride][4 or 8]                                  (out), env_stride = n_envs rounded up to 64
+ *   err_out    device uint32 (may be NULL): the MG_ERR_* bits of this call
+ * Limits: width, height <= 64 and view_size in {3, 5, 7} (what the array was laid out for; MG_EINVAL / MG_EUNSUPPORTED
+ * beyond), any n_envs.  Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two
+ * threads) race on it — serialise them. */
+int mg_step_noalloc(const mg_config* cfg, int device, void* hip_stream, uint64_t step_index, const uint8_t* cells,
+                    const void* actions, uint32_t* env_state, uint8_t* obs_image, double* reward, uint8_t* dir_done,
+                    uint32_t* err_out);
+
 int mg_get_buffers(mg_handle* h, mg_buffers* out);
 
 /* Stream control: by default the handle owns a stream; mg_set_stream adopts the caller's
@@ -300,6 +328,10 @@ int mg_get_launch_info(mg_handle* h, int32_t* path, int32_t* block_threads, int3
 /* Test hook (no reference counterpart): MiniGridEnv._reward() = 1 - 0.9*(s/max_steps) as the
  * DEVICE computes it, for s = 0..max_steps, copied to host `out` (max_steps+1 doubles). */
 int mg_debug_device_rewards(int device, int32_t max_steps, double* out);
+
+/* Test hook (no reference counterpart): sqrt(k), k = 0..n, as mg_step_noalloc's table-building kernel evaluates it on the
+ * device (np.linalg.norm of an integer vector, v8_robust_ppo.py:192), copied to host `out` (n+1 doubles). */
+int mg_debug_device_sqrt(int device, int32_t n, double* out);
 
 /* Test hook, host only (no GPU call, no reference counterpart): evaluates the kernels' bitmask
  * form of Grid.process_vis on n opacity patterns so that it can be compared

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <pthread.h>
 #include <algorithm>
 #include <string>
 #include <type_traits>
@@ -822,6 +823,57 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
 #include "mg_dyn.h"
 
 // ---------------------------------------------------------------------------------------------
+// mg_step_noalloc: the per-GPU scratch its kernels use instead of a handle's hipMalloc'ed tables.
+// Layout: [0, 256) the error word (+ padding), [256, 256 + 32 KB) the goal-distance LUT (W*H f64, W, H <= 64),
+// then the padded map ((W + 2(V-1)) * (H + 2(V-1)) u32, V <= 7: at most 23,104 B).  Host code never touches the
+// array by name: it goes through the per-device address hipGetSymbolAddress returned (noalloc_device).
+// ---------------------------------------------------------------------------------------------
+constexpr size_t kScratchBytes = 64 * 1024;
+constexpr size_t kScratchDist = 256, kScratchMap = 256 + 64 * 64 * 8;
+static_assert(kScratchMap + (64 + 12) * (64 + 12) * 4 <= kScratchBytes, "scratch holds the largest grid the kernels take");
+static __device__ __align__(256) unsigned char g_scratch[kScratchBytes];
+
+// One workgroup turns the caller's layout (device uint8[H*W*3], the cells mg_set_static_map takes from the host) into
+// the padded map and the distance LUT, exactly as mg_set_static_map builds them on the host.  Unknown or mutable cell
+// types cannot be refused from the device: they are flagged (MG_ERR_BAD_MAP) and treated as walls.
+__global__ __launch_bounds__(256) void noalloc_prep(const uint8_t* cells, int W, int H, int V, int A, uint32_t* err,
+                                                    double* dist, uint32_t* map) {
+  __shared__ unsigned int goal_key, n_free, bad;
+  const int pad = V - 1, PW = W + 2 * pad, PH = H + 2 * pad;
+  if (threadIdx.x == 0) { goal_key = 0xFFFFFFFFu; n_free = 0; bad = 0; }
+  __syncthreads();
+  const uint32_t wall = (uint32_t)MG_T_WALL | (5u << 8) | F_OPAQUE;   // Grid.slice's out-of-bounds Wall() (multigrid.py:315)
+  for (int i = threadIdx.x; i < PW * PH; i += blockDim.x) {
+    const int x = i % PW - pad, y = i / PW - pad;
+    uint32_t w = wall;
+    if (x >= 0 && y >= 0 && x < W && y < H) {
+      const uint8_t* c = cells + ((size_t)y * W + x) * 3;
+      w = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+      switch (c[0]) {
+        case MG_T_UNSEEN: case MG_T_EMPTY: w = (uint32_t)MG_T_EMPTY | F_FREE; atomicAdd(&n_free, 1u); break;
+        case MG_T_WALL: w |= F_OPAQUE; break;
+        case MG_T_GOAL: w |= F_KILL | F_GOAL; atomicMin(&goal_key, (unsigned int)(x * H + y)); break;   // first goal, x-major (v8:159-169)
+        case MG_T_LAVA: if (c[1] == 5) w = (uint32_t)MG_T_WALL | (5u << 8); w |= F_KILL; break;         // grey lava = LavaWall
+        default: w = wall; atomicOr(&bad, 1u); break;
+      }
+    }
+    map[i] = w;
+  }
+  __syncthreads();
+  const int gx = goal_key == 0xFFFFFFFFu ? 13 : (int)(goal_key / (unsigned int)H);
+  const int gy = goal_key == 0xFFFFFFFFu ? 13 : (int)(goal_key % (unsigned int)H);
+  for (int i = threadIdx.x; i < W * H; i += blockDim.x) {
+    const long dx = i % W - gx, dy = i / W - gy;
+    dist[i] = __dsqrt_rn((double)(dx * dx + dy * dy));   // np.linalg.norm (v8:192); checked against the host's sqrt for
+  }                                                       // every reachable argument by tests (mg_debug_device_sqrt)
+  if (threadIdx.x == 0 && (bad || n_free < (unsigned int)A)) atomicOr(err, MG_ERR_BAD_MAP);
+}
+
+__global__ void sqrt_probe(int n, double* out) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= n; k += gridDim.x * blockDim.x) out[k] = __dsqrt_rn((double)k);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 thread_local std::string g_err;
@@ -1159,6 +1211,8 @@ int enable_dynamic(mg_handle* h, const std::vector<uint8_t>& kinds, int gx, int 
 
 }  // namespace
 
+namespace { int noalloc_warm(int device); }
+
 extern "C" {
 
 const char* mg_last_error(void) { return g_err.c_str(); }
@@ -1217,6 +1271,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   DeviceGuard g(device);
   if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
 
+  (void)noalloc_warm(device);   // mg_step_noalloc's per-device set-up, so that its own calls find it done (a failure is reported there)
   mg_handle* h = new mg_handle();
   h->cfg = c; h->device = device; h->var = var; h->t = 0; h->have_map = h->have_reset = false;
   h->dynamic = false; h->dvar = dvar; h->GW = (c.width * c.height + 3) / 4;
@@ -1522,6 +1577,129 @@ int mg_step_random(mg_handle* h, uint8_t* actions_out) {
   int rc = launch(h, OP_STEP, nullptr, nullptr, nullptr, nullptr, nullptr, 1, actions_out);
   if (rc == MG_OK) h->t += 1;
   return rc;
+}
+
+// ---- mg_step_noalloc ---------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+// Per-device set-up of the allocation-free entry point: the address of THIS device's copy of g_scratch (every GPU holds
+// its own copy of a __device__ array at its own address), its CU count, and the LDS attribute of the kernels it may
+// launch.  Done once per device, with that device current; afterwards host code uses `ptr` only.
+constexpr int kMaxDevices = 64;
+struct NoAllocDevice { bool ready; unsigned char* ptr; int n_cu; };
+NoAllocDevice g_noalloc[kMaxDevices];
+pthread_mutex_t g_noalloc_mu = PTHREAD_MUTEX_INITIALIZER;
+
+int noalloc_device(int device, NoAllocDevice* out) {
+  if (device < 0 || device >= kMaxDevices) return fail(MG_EINVAL, "bad device index");
+  pthread_mutex_lock(&g_noalloc_mu);
+  NoAllocDevice& d = g_noalloc[device];
+  int rc = MG_OK;
+  if (!d.ready) {
+    void* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_scratch));   // needs `device` current: the caller's DeviceGuard
+    if (e != hipSuccess || !ptr) rc = fail(MG_EHIP, std::string("hipGetSymbolAddress(g_scratch): ") + hipGetErrorString(e));
+    int n_cu = 256;
+    if (rc == MG_OK) {
+      (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device);
+      for (const Variant& v : kVariants) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(v.generic[1]), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+        if (e != hipSuccess) { rc = fail(MG_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); break; }
+      }
+    }
+    if (rc == MG_OK) { d.ptr = static_cast<unsigned char*>(ptr); d.n_cu = n_cu < 1 ? 1 : n_cu; d.ready = true; }
+  }
+  if (rc == MG_OK) *out = d;
+  pthread_mutex_unlock(&g_noalloc_mu);
+  return rc;
+}
+
+int noalloc_warm(int device) { NoAllocDevice d; return noalloc_device(device, &d); }
+
+}  // namespace
+
+extern "C" {
+
+int mg_step_noalloc(const mg_config* cfg, int device, void* hip_stream, uint64_t step_index, const uint8_t* cells,
+                    const void* actions, uint32_t* env_state, uint8_t* obs_image, double* reward, uint8_t* dir_done,
+                    uint32_t* err_out) {
+  if (!cfg || !cells || !actions || !env_state || !obs_image || !reward || !dir_done) return fail(MG_EINVAL, "null argument");
+  const mg_config& c = *cfg;
+  // sizes beyond what the per-GPU scratch array was laid out for
+  if (c.width < 3 || c.height < 3 || c.width > 64 || c.height > 64)
+    return fail(MG_EINVAL, "mg_step_noalloc: width/height must be in [3,64] (the scratch array holds one 64x64 distance table)");
+  if (c.view_size != 3 && c.view_size != 5 && c.view_size != 7)
+    return fail(MG_EUNSUPPORTED, "mg_step_noalloc: view_size must be 3, 5 or 7 (the scratch array holds a map padded by at most 6 cells)");
+  if (c.env_kind != MG_KIND_STATIC) return fail(MG_EUNSUPPORTED, "mg_step_noalloc: shared static layouts only (env_kind = MG_KIND_STATIC)");
+  if (c.emit_env_reward) return fail(MG_EUNSUPPORTED, "mg_step_noalloc: no env_reward output");
+  if (c.n_envs < 1) return fail(MG_EINVAL, "n_envs must be >= 1");
+  if (c.max_steps < 1 || c.max_steps > 65534) return fail(MG_EINVAL, "max_steps must be in [1,65534]");
+  if (c.shaping_kind < MG_SHAPING_NONE || c.shaping_kind > MG_SHAPING_V7) return fail(MG_EINVAL, "unknown shaping_kind");
+  if (c.env_id_base < 0 || (uint64_t)c.env_id_base + (uint64_t)c.n_envs > 0xFFFFFFFFull)
+    return fail(MG_EINVAL, "global env ids must fit 32 bits");
+  const Variant* var = nullptr;
+  for (const Variant& v : kVariants)
+    if (v.A == c.n_agents && v.V == c.view_size) var = &v;
+  if (!var) return fail(MG_EUNSUPPORTED, "no kernel instantiated for this (n_agents, view_size)");
+  const int PW = c.width + 2 * (c.view_size - 1), PH = c.height + 2 * (c.view_size - 1);
+  if (kScratchMap + (size_t)PW * PH * 4 > kScratchBytes || (size_t)c.width * c.height * 8 > kScratchMap - kScratchDist)
+    return fail(MG_EINVAL, "mg_step_noalloc: layout does not fit the scratch array");
+
+  DeviceGuard g(device);
+  if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
+  NoAllocDevice d;
+  int rc = noalloc_device(device, &d);
+  if (rc != MG_OK) return rc;
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  uint32_t* err = reinterpret_cast<uint32_t*>(d.ptr);
+  double* dist = reinterpret_cast<double*>(d.ptr + kScratchDist);
+  uint32_t* map = reinterpret_cast<uint32_t*>(d.ptr + kScratchMap);
+
+  // the array keeps the last call's contents: the error word starts at zero, map and table are rewritten in full
+  HIP_TRY(hipMemsetAsync(err, 0, 4, stream));
+  hipLaunchKernelGGL(noalloc_prep, dim3(1), dim3(256), 0, stream, cells, c.width, c.height, c.view_size, c.n_agents, err, dist, map);
+  HIP_TRY(hipGetLastError());
+
+  mg_handle hh;                      // geometry helpers read a handle; this one lives on the stack and owns nothing
+  hh.cfg = c; hh.device = device; hh.var = var; hh.use_table = false; hh.n_entries = 0;
+  hh.stride = (c.n_envs + 63) / 64 * 64; hh.n_chunks = hh.stride / 64; hh.PW = PW; hh.PH = PH; hh.n_cu = d.n_cu;
+  hh.dynamic = false; hh.full_obs = false;
+  hh.cfg.kernel_path = MG_PATH_GENERIC;
+  Params p;
+  memset(&p, 0, sizeof(p));
+  p.W = c.width; p.H = c.height; p.max_steps = c.max_steps; p.see_through = c.see_through_walls;
+  p.competitive = (c.n_agents == 1) ? 1 : c.competitive;
+  p.shaping = c.shaping_kind; p.auto_reset = c.auto_reset; p.dd_bytes = (c.n_agents + 1 <= 4) ? 4 : 8;
+  p.op = OP_STEP; p.PW = PW; p.PH = PH;
+  p.n_envs = c.n_envs; p.stride = hh.stride; p.n_chunks = hh.n_chunks;
+  p.gid_base = (uint64_t)c.env_id_base; p.t = step_index;
+  p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32);
+  p.map_pad = map; p.dist_lut = dist;
+  p.actions = reinterpret_cast<const uint32_t*>(actions);
+  p.obs_image = obs_image; p.reward = reward; p.dir_done = dir_done; p.env_state = env_state; p.err = err;
+  p.nt_obs = hh.n_chunks > (int64_t)d.n_cu * 16 * kUpfront ? 0xFF : 0;
+  int nw; unsigned grid; size_t lds;
+  launch_geometry(&hh, false, &nw, &grid, &lds);
+  hipLaunchKernelGGL(var->generic[1], dim3(grid), dim3(nw * kWave), lds, stream, p);
+  HIP_TRY(hipGetLastError());
+  if (err_out) HIP_TRY(hipMemcpyAsync(err_out, err, 4, hipMemcpyDeviceToDevice, stream));
+  return MG_OK;
+}
+
+// Test hook: sqrt(k) for k = 0..n as noalloc_prep evaluates it on the device, copied to host `out` (n + 1 doubles).
+int mg_debug_device_sqrt(int device, int32_t n, double* out) {
+  if (!out || n < 0) return fail(MG_EINVAL, "bad argument");
+  DeviceGuard g(device);
+  if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
+  double* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, ((size_t)n + 1) * 8));
+  hipLaunchKernelGGL(sqrt_probe, dim3(64), dim3(256), 0, 0, (int)n, d);
+  hipError_t e = hipMemcpy(out, d, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(MG_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+  return MG_OK;
 }
 
 int mg_get_buffers(mg_handle* h, mg_buffers* out) {

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, 'libmgrid.so')
 MG_OK = 0
 SHAPING_NONE, SHAPING_V8 = 0, 1
 PATH_AUTO, PATH_GENERIC, PATH_TABLE = 0, 1, 2
-ERR_BAD_ACTION, ERR_BAD_RESPAWN, ERR_BAD_ORDER, ERR_MISSING_DRAW = 1, 2, 4, 8
+ERR_BAD_ACTION, ERR_BAD_RESPAWN, ERR_BAD_ORDER, ERR_MISSING_DRAW, ERR_BAD_MAP = 1, 2, 4, 8, 16
 KIND_STATIC, KIND_DOORKEY, KIND_CLUTTERED, KIND_MEETUP, KIND_FOURROOMS = 0, 1, 2, 3, 4
 KINDS = {'static': KIND_STATIC, 'doorkey': KIND_DOORKEY, 'cluttered': KIND_CLUTTERED, 'meetup': KIND_MEETUP,
          'fourrooms': KIND_FOURROOMS}
@@ -77,6 +77,8 @@ SYMBOLS = {
     'mg_check_errors': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     'mg_get_goal': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'mg_get_launch_info': (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 4),
+    'mg_step_noalloc': (C.c_int, [C.POINTER(MgConfig), C.c_int, C.c_void_p, C.c_uint64] + [C.c_void_p] * 7),
+    'mg_debug_device_sqrt': (C.c_int, [C.c_int, C.c_int32, C.c_void_p]),
     'mg_debug_device_rewards': (C.c_int, [C.c_int, C.c_int32, C.c_void_p]),
     'mg_debug_vis_masks': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     'mg_last_error': (C.c_char_p, []),
