@@ -302,6 +302,24 @@ int mg_step_noalloc(const mg_config* cfg, int device, void* hip_stream, uint64_t
                     const void* actions, uint32_t* env_state, uint8_t* obs_image, double* reward, uint8_t* dir_done,
                     uint32_t* err_out);
 
+/* Fused synthetic rollout: n_steps consecutive mg_step_random steps in ONE kernel launch (the "synthetic random-action
+ * rollouts" BASELINE.json's metric is quoted on; the reference's counterpart is a loop of env.step(random actions),
+ * v8_robust_ppo.py:237-271 with the policy replaced by a uniform draw).  Each wavefront keeps its 64 envs' state in
+ * registers over the n_steps steps; step k's outputs go to slot k of the caller's trajectory buffers, laid out like the
+ * handle's own (device pointers, env_stride and dir_done_bytes as in mg_buffers):
+ *   obs_image uint8 [n_steps][A][env_stride][V*V*3]     reward double [n_steps][A][env_stride]
+ *   dir_done  uint8 [n_steps][env_stride][dir_done_bytes]   actions uint8 [n_steps][env_stride][MG_SLOTS(A)] (may be NULL)
+ * Afterwards the handle is exactly where n_steps calls of mg_step_random would have left it: env_state, step index, and
+ * its own obs_image / reward / dir_done buffers hold the last step.  Shared-map handles without env_reward output only
+ * (MG_EUNSUPPORTED otherwise); auto-reset and shaping as configured. */
+typedef struct mg_rollout_out {
+  uint8_t* obs_image;
+  double*  reward;
+  uint8_t* dir_done;
+  uint8_t* actions;
+} mg_rollout_out;
+int mg_rollout_random(mg_handle* h, int32_t n_steps, const mg_rollout_out* out);
+
 int mg_get_buffers(mg_handle* h, mg_buffers* out);
 
 /* Stream control: by default the handle owns a stream; mg_set_stream adopts the caller's

@@ -266,6 +266,24 @@ class BatchedMultiGrid:
     _lib.check(self.L.mg_step_random(self.h, ptr))
     return self.obs(), self.reward, self.done, {}
 
+  def rollout_random(self, n_steps, out=None, store_actions=True):
+    """n_steps fused steps with on-device uniform random actions in one launch (mg_rollout_random).  Returns the
+    trajectory dict {'image' uint8[K, A, N, V, V, 3], 'direction' uint8[K, A, N] (view), 'reward' float64[K, A, N],
+    'done' uint8[K, N] (view), 'actions' uint8[K, N, A] (view) or None}; pass the dict back as `out` to reuse its buffers."""
+    K, A, V, S, n, dev = int(n_steps), self.n_agents, self.view_size, self.stride, self.n_envs, self.device
+    if out is None or out['_K'] != K:
+      ddb = self._dir_done.shape[1]
+      out = {'_K': K, '_obs': torch.empty((K, A, S, V, V, 3), dtype=torch.uint8, device=dev),
+             '_reward': torch.empty((K, A, S), dtype=torch.float64, device=dev),
+             '_dd': torch.empty((K, S, ddb), dtype=torch.uint8, device=dev),
+             '_act': torch.empty((K, S, self.slots), dtype=torch.uint8, device=dev) if store_actions else None}
+      out.update(image=out['_obs'][:, :, :n], reward=out['_reward'][:, :, :n], direction=out['_dd'][:, :n, :A].permute(0, 2, 1),
+                 done=out['_dd'][:, :n, A], actions=None if out['_act'] is None else out['_act'][:, :n, :A])
+    ro = _lib.MgRolloutOut(out['_obs'].data_ptr(), out['_reward'].data_ptr(), out['_dd'].data_ptr(),
+                           out['_act'].data_ptr() if out['_act'] is not None else None)
+    _lib.check(self.L.mg_rollout_random(self.h, K, C.byref(ro)))
+    return out
+
   def sync(self):
     _lib.check(self.L.mg_sync(self.h))
 

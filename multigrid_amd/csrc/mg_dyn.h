@@ -697,7 +697,7 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up t
   // before the LDS tables are filled
   const int64_t cstride = (int64_t)gridDim.x * nw;
   int64_t c = (int64_t)blockIdx.x * nw + wv;
-  DynIn<A, PRE> cur, nxt;
+  DynIn<A, PRE> cur = {}, nxt;
   if (c < p.n_chunks) dyn_load<A, PRE>(p, c * kWave, lane, cur);
 
   for (int i = tid; i < 256; i += blockDim.x) lut[i] = kind_word((uint32_t)i);
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up t
 #endif
   constexpr int kLo = (kObs + A + 3) < 63 ? (kObs + A + 3) : 63;   // the grid rows go back only when a lane changed its grid
   constexpr int kFull = A + 3;                                     // fully observed: at least these
-  if (c < p.n_chunks) dyn_wait<A, 0, PRE>(cur);
+  dyn_wait<A, 0, PRE>(cur);      // on every path, right after the barrier (see mg_kernel)
   for (; c < p.n_chunks; c += cstride) {
     const int64_t cn = c + cstride;
     const bool more = cn < p.n_chunks;          // wave-uniform

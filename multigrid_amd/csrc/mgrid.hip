@@ -103,6 +103,12 @@ struct Params {
   const uint16_t* scatter;     // int8x2 per (env, scattered object): injected layout draws
   uint32_t* aux;               // [stride][4]  MEETUP goal positions + past distances
   uint8_t* obs_full;           // [stride][W*H*3]  fully observed obs
+  // fused K-step rollout (mg_rollout_random): step k of the launch writes slot k of the caller's trajectory buffers
+  int32_t n_roll, roll_pad;
+  uint8_t* traj_obs;           // [K][A][stride][V*V*3]
+  double* traj_reward;         // [K][A][stride]
+  uint8_t* traj_dd;            // [K][stride][dd_bytes]
+  uint32_t* traj_actions;      // [K][stride][slot words], may be null
 };
 
 struct U4 { uint32_t x, y, z, w; };
@@ -309,7 +315,7 @@ __device__ __forceinline__ void store_vec16(uint4* dst, const uint4 v, bool nt) 
 // Stage the 64 images of this wave in LDS and stream them to HBM as one contiguous chunk.
 template <int A, int V>
 __device__ __forceinline__ void emit_obs(pd_t<A> pd, int a, uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t vm,
-                                         uint32_t* stage, int lane, uint8_t* gchunk, bool nt) {
+                                         uint32_t* stage, int lane, uint8_t* gchunk, bool nt, uint8_t* gchunk2 = nullptr) {
   constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
   const uint32_t me = pd_get(pd, a);
   const int x = aw_x(me), y = aw_y(me), d = aw_d(me);
@@ -365,6 +371,14 @@ __device__ __forceinline__ void emit_obs(pd_t<A> pd, int a, uint32_t (&s)[ViewGe
 #else
     if (idx < NV) store_vec16(dst + idx, src[idx], nt);
 #endif
+  }
+  if (gchunk2) {                               // wave-uniform; only the fused rollout ever passes one
+    uint4* dst2 = reinterpret_cast<uint4*>(gchunk2);
+#pragma unroll
+    for (int i = 0; i < (NV + kWave - 1) / kWave; ++i) {
+      const int idx = i * kWave + lane;
+      if (idx < NV) store_vec16(dst2 + idx, src[idx], false);
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -566,34 +580,24 @@ __device__ __forceinline__ pd_t<A> fixed_place(const Params& p, pd_t<A> pd, int 
   return pd;
 }
 
-// One chunk (64 envs) of one step()/reset().
-template <int A, int V, bool TAB, bool FAST>
-__device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, const double* dist, const uint32_t* table,
-                                         const uint16_t* cidx, uint32_t* stage, int lane, int64_t env0,
-                                         const ChunkIn& in, uint32_t& err_acc) {
+// One step()/reset() of one chunk (64 envs) whose state is in registers: pd = (x, y, dir) of every agent, shw = the shaper
+// bits of the agent words, st = step_count | done bits << 16, actw = the actions (3 bits per agent).  The outputs go to
+// p.obs_image / p.reward / p.dir_done (and p.env_state when store_state); ROLL = a step of the fused rollout
+// (mg_rollout_kernel): free-running like FAST, actions drawn on the device, and on its last step a second set of
+// destinations (the handle's own buffers, *2 below) besides the trajectory slot.
+template <int A, int V, bool TAB, bool FAST, bool ROLL = false>
+__device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map, const double* dist, const uint32_t* table,
+                                           const uint16_t* cidx, uint32_t* stage, int lane, int64_t env0,
+                                           pd_t<A>& pd, uint32_t (&shw)[A], uint32_t& st, uint32_t actw, bool store_state,
+                                           uint32_t& err_acc, uint8_t* obs2 = nullptr, double* reward2 = nullptr,
+                                           uint8_t* dd2 = nullptr) {
+  static_assert(!ROLL || FAST, "the rollout is a free-running step");
   constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
   const int64_t n = env0 + lane;
   const bool active = n < p.n_envs;
   const uint32_t gid = (uint32_t)(p.gid_base + (uint64_t)n);
   const int pad = (p.PW - p.W) >> 1;
-
-  pd_t<A> pd = pd_t<A>{};       // x | y<<6 | dir<<12 of every agent, 14 bits each
-  uint32_t shw[A];              // v8 shaper bits of each agent word (bits 14..29)
-  uint32_t win[6];
-  if (A == 3) { win[0] = in.q.x; win[1] = in.q.y; win[2] = in.q.z; win[3] = in.q.w; win[4] = 0u; win[5] = 0u; }
-  else {
-    win[0] = in.w0; win[1] = in.w1; win[2] = in.w2; win[3] = in.w3; win[4] = in.w4; win[5] = in.w5;
-  }
-  uint32_t actw = 0, st = win[A], err = 0;
-#pragma unroll
-  for (int a = 0; a < A; ++a) {
-    actw |= min(((a < 4 ? in.act >> (8 * a) : in.act2 >> (8 * (a - 4)))) & 255u, 7u) << (3 * a);
-    // keep every later LDS index in range whatever the buffer holds
-    const uint32_t w = win[a];
-    const uint32_t cx = min(w & 63u, (uint32_t)(p.W - 1)), cy = min((w >> 6) & 63u, (uint32_t)(p.H - 1));
-    pd = pd_set(pd, a, cx | (cy << 6) | (w & 0x3000u));
-    shw[a] = w & ~AW_POSDIR;
-  }
+  uint32_t err = 0;
   uint32_t done_flag = 0;
 
   const bool is_step = FAST || p.op == OP_STEP;
@@ -601,7 +605,7 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
   const uint32_t* const inj_spawn = FAST ? nullptr : p.reset_spawn;
   if (is_step) {
     // ---- actions -------------------------------------------------------------------------
-    if (!FAST && p.random_actions) actw = draw_actions<A>(p, n, gid, active);
+    if (ROLL || (!FAST && p.random_actions)) actw = draw_actions<A>(p, n, gid, active);
     // ---- step_count += 1 (multigrid.py:968) ----------------------------------------------
     uint32_t step = (st & 0xFFFFu) + 1u;
     uint32_t dbits = st >> 16;
@@ -666,7 +670,8 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
 #pragma unroll
       for (int a = 0; a < A; ++a) {
         const int64_t i = (int64_t)a * p.stride + n;
-        p.reward[i] = out_rew[a];
+        if (ROLL) __builtin_nontemporal_store(out_rew[a], p.reward + i); else p.reward[i] = out_rew[a];
+        if (ROLL && reward2) reward2[i] = out_rew[a];
         if (!FAST && p.env_reward) p.env_reward[i] = rew[a];
       }
     }
@@ -697,15 +702,17 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
   }
 
   if (active) {
-    uint32_t wout[A];
+    if (store_state) {
+      uint32_t wout[A];
 #pragma unroll
-    for (int a = 0; a < A; ++a) wout[a] = shw[a] | pd_get(pd, a);
-    if (A == 3) {
-      reinterpret_cast<uint4*>(p.env_state)[n] = make_uint4(wout[0], wout[A > 1 ? 1 : 0], wout[A > 2 ? 2 : 0], st);
-    } else {
+      for (int a = 0; a < A; ++a) wout[a] = shw[a] | pd_get(pd, a);
+      if (A == 3) {
+        reinterpret_cast<uint4*>(p.env_state)[n] = make_uint4(wout[0], wout[A > 1 ? 1 : 0], wout[A > 2 ? 2 : 0], st);
+      } else {
 #pragma unroll
-      for (int a = 0; a < A; ++a) p.env_state[n * (A + 1) + a] = wout[a];
-      p.env_state[n * (A + 1) + A] = st;
+        for (int a = 0; a < A; ++a) p.env_state[n * (A + 1) + a] = wout[a];
+        p.env_state[n * (A + 1) + A] = st;
+      }
     }
     // obs['direction'][a] (multigrid.py:1083) for every agent + the collective done flag: one store
     uint64_t dd = (uint64_t)done_flag << (8 * A);
@@ -713,6 +720,10 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
     for (int a = 0; a < A; ++a) dd |= (uint64_t)aw_d(pd_get(pd, a)) << (8 * a);
     if (A + 1 <= 4) reinterpret_cast<uint32_t*>(p.dir_done)[n] = (uint32_t)dd;
     else reinterpret_cast<uint64_t*>(p.dir_done)[n] = dd;
+    if (ROLL && dd2) {
+      if (A + 1 <= 4) reinterpret_cast<uint32_t*>(dd2)[n] = (uint32_t)dd;
+      else reinterpret_cast<uint64_t*>(dd2)[n] = dd;
+    }
     err_acc |= err;
   }
 
@@ -724,9 +735,44 @@ __device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, c
     uint64_t vm;
     if (TAB) table_view<V>(p, table, cidx, pd_get(pd, a), s, vm);
     else static_view<V>(p, map, pd_get(pd, a), s, vm);
-    emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB, ((p.nt_obs >> a) & 1) != 0);
+    emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB, ((p.nt_obs >> a) & 1) != 0,
+                   (ROLL && obs2) ? obs2 + ((int64_t)a * p.stride + env0) * ROWB : nullptr);
   }
 #endif
+}
+
+// The agent words / step word / actions of one chunk as loaded -> registers.
+template <int A>
+__device__ __forceinline__ void unpack_chunk(const Params& p, const ChunkIn& in, pd_t<A>& pd, uint32_t (&shw)[A], uint32_t& st,
+                                             uint32_t& actw) {
+  uint32_t win[6];
+  if (A == 3) { win[0] = in.q.x; win[1] = in.q.y; win[2] = in.q.z; win[3] = in.q.w; win[4] = 0u; win[5] = 0u; }
+  else {
+    win[0] = in.w0; win[1] = in.w1; win[2] = in.w2; win[3] = in.w3; win[4] = in.w4; win[5] = in.w5;
+  }
+  pd = pd_t<A>{};               // x | y<<6 | dir<<12 of every agent, 14 bits each
+  actw = 0;
+  st = win[A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    actw |= min(((a < 4 ? in.act >> (8 * a) : in.act2 >> (8 * (a - 4)))) & 255u, 7u) << (3 * a);
+    // keep every later LDS index in range whatever the buffer holds
+    const uint32_t w = win[a];
+    const uint32_t cx = min(w & 63u, (uint32_t)(p.W - 1)), cy = min((w >> 6) & 63u, (uint32_t)(p.H - 1));
+    pd = pd_set(pd, a, cx | (cy << 6) | (w & 0x3000u));
+    shw[a] = w & ~AW_POSDIR;              // v8 shaper bits of the agent word (bits 14..29)
+  }
+}
+
+// One chunk (64 envs) of one step()/reset().
+template <int A, int V, bool TAB, bool FAST>
+__device__ __forceinline__ void do_chunk(const Params& p, const uint32_t* map, const double* dist, const uint32_t* table,
+                                         const uint16_t* cidx, uint32_t* stage, int lane, int64_t env0,
+                                         const ChunkIn& in, uint32_t& err_acc) {
+  pd_t<A> pd;
+  uint32_t shw[A], st, actw;
+  unpack_chunk<A>(p, in, pd, shw, st, actw);
+  step_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, env0, pd, shw, st, actw, true, err_acc);
 }
 
 template <int A, int V, bool TAB, bool FAST>
@@ -761,6 +807,10 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
   for (int i = tid; i < p.W * p.H; i += blockDim.x) dist[i] = p.dist_lut[i];
 #endif
   __syncthreads();
+  // The first chunk's inputs are retired here, on every path and before anything else is requested: the LDS fills above
+  // have long covered their latency.  (A wait under `if (c < n_chunks)` made hipcc copy the registers into the asm
+  // operands before the wait and back after it, i.e. read them while the lint's CFG still had them in flight.)
+  wait_chunk<0>(cur);
 
   uint32_t* stage = stage_all + wv * (kWave * ROWB / 4);
   uint32_t err = 0;
@@ -799,13 +849,12 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
     if (h1) load_chunk<A, FAST>(p, c1 * kWave, lane, in1);
     if (h2) load_chunk<A, FAST>(p, c2 * kWave, lane, in2);
     if (h3) load_chunk<A, FAST>(p, c3 * kWave, lane, in3);
-    wait_chunk<0>(cur); wait_chunk<0>(in1); wait_chunk<0>(in2); wait_chunk<0>(in3);
+    wait_chunk<0>(in1); wait_chunk<0>(in2); wait_chunk<0>(in3);
     if (c < p.n_chunks) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, c * kWave, cur, err);
     if (h1) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, c1 * kWave, in1, err);
     if (h2) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, c2 * kWave, in2, err);
     if (h3) do_chunk<A, V, TAB, FAST>(p, map, dist, table, cidx, stage, lane, c3 * kWave, in3, err);
   } else {
-    if (c < p.n_chunks) wait_chunk<0>(cur);
     for (; c < p.n_chunks; c += cstride) {
       const int64_t cn = c + cstride;
       const bool more = cn < p.n_chunks;          // wave-uniform
@@ -814,6 +863,99 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
       if (more) {
         if (FAST || p.op == OP_STEP) wait_chunk<kStep>(nxt); else wait_chunk<kReset>(nxt);
         cur = nxt;
+      }
+    }
+  }
+  if (err) atomicOr(p.err, err);
+}
+
+// Fused K-step synthetic rollout (mg_rollout_random): p.n_roll consecutive free-running steps with on-device random
+// actions — exactly what p.n_roll calls of mg_step_random compute — in ONE launch.  A wave loads its chunk's env_state
+// once, keeps it in registers over the K steps and writes it back once; step k's obs / rewards / dir-done / actions go
+// to slot k of the caller's trajectory buffers (write-once data: non-temporal stores), the last step's also to the
+// handle's own buffers.  What this removes from a step: the launch ramp and drain (~8 us per launch, the whole cost of
+// a step below ~100k envs) and the env_state / action traffic.
+template <int A, int V, bool TAB>
+__global__ __launch_bounds__(kMaxBlock) void mg_rollout_kernel(const Params p) {
+  constexpr int ROWB = ViewGeom<V>::ROWB, ENTW = ViewGeom<V>::ENTW;
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int nw = blockDim.x >> 6;
+  uint32_t* stage_all = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* table = reinterpret_cast<uint32_t*>(smem + (size_t)nw * kWave * ROWB);
+  double* dist = reinterpret_cast<double*>(table + (TAB ? p.n_entries * ENTW : 0));
+  uint32_t* map = reinterpret_cast<uint32_t*>(dist + p.W * p.H);
+  uint16_t* cidx = reinterpret_cast<uint16_t*>(map + p.PW * p.PH);
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
+  if (TAB) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.view_table);
+    uint4* dst = reinterpret_cast<uint4*>(table);
+    for (int i = tid; i < p.n_entries * ENTW / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = tid; i < p.W * p.H; i += blockDim.x) cidx[i] = p.cell_index[i];
+  }
+  for (int i = tid; i < p.PW * p.PH; i += blockDim.x) map[i] = p.map_pad[i];
+  for (int i = tid; i < p.W * p.H; i += blockDim.x) dist[i] = p.dist_lut[i];
+  __syncthreads();
+
+  uint32_t* stage = stage_all + wv * (kWave * ROWB / 4);
+  uint32_t err = 0;
+  const int64_t cstride = (int64_t)gridDim.x * nw;
+  const int64_t slot_obs = (int64_t)A * p.stride * ROWB, slot_rew = (int64_t)A * p.stride;
+  const int64_t slot_dd = p.stride * p.dd_bytes, slot_act = p.stride * kSlotWords<A>;
+  Params q = p;
+  // A wave owns up to four chunks (one per "window" of cstride chunks, like the launch-resident step kernel) and takes
+  // them through the K steps TOGETHER — step k of all its chunks, then step k + 1 — so that the whole chip writes one
+  // trajectory slot at a time, as one sweeping front of contiguous regions.  (One chunk per wave for all K steps, then
+  // the next chunk, scatters the writes over K slots x all agents and reaches only ~4.5 TB/s.)  The state of a chunk
+  // is six registers; the four sets rotate through set 0, so the big step body exists once.
+  struct St { pd_t<A> pd; uint32_t shw[A]; uint32_t st; };
+  constexpr int NJ = 4;
+  for (int64_t g0 = (int64_t)blockIdx.x * nw + wv; g0 < p.n_chunks; g0 += cstride * NJ) {
+    St s0, s1, s2, s3;
+    int nj = 0;
+    auto load_state = [&](int jj, St& s) {
+      const int64_t c = g0 + jj * cstride;
+      ChunkIn in;
+      zero_chunk(in);
+      if (c < p.n_chunks) {                      // wave-uniform
+        nj = jj + 1;
+        const int64_t n = c * kWave + lane;
+        if (A == 3) {
+          const uint4 w = reinterpret_cast<const uint4*>(p.env_state)[n];
+          in.q = u32x4{w.x, w.y, w.z, w.w};
+        } else {
+          const uint32_t* sp = p.env_state + n * (A + 1);
+          in.w0 = sp[0];
+          if (A >= 1) in.w1 = sp[1];
+          if (A >= 2) in.w2 = sp[2];
+          if (A >= 3) in.w3 = sp[3];
+          if (A >= 4) in.w4 = sp[4];
+          if (A >= 5) in.w5 = sp[5];
+        }
+      }
+      uint32_t actw;
+      unpack_chunk<A>(p, in, s.pd, s.shw, s.st, actw);
+    };
+    load_state(0, s0); load_state(1, s1); load_state(2, s2); load_state(3, s3);
+#pragma unroll 1
+    for (int k = 0; k < p.n_roll; ++k) {
+      const bool last = k == p.n_roll - 1;
+      q.t = p.t + (uint64_t)k;
+      q.obs_image = p.traj_obs + k * slot_obs;
+      q.reward = p.traj_reward + k * slot_rew;
+      q.dir_done = p.traj_dd + k * slot_dd;
+      q.actions_out = p.traj_actions ? p.traj_actions + k * slot_act : nullptr;
+#pragma unroll 1
+      for (int jj = 0; jj < nj; ++jj) {
+        step_chunk<A, V, TAB, true, true>(q, map, dist, table, cidx, stage, lane, (g0 + jj * cstride) * kWave, s0.pd, s0.shw, s0.st,
+                                          0u, last, err, last ? p.obs_image : nullptr, last ? p.reward : nullptr,
+                                          last ? p.dir_done : nullptr);
+        if (nj > 1) {                            // rotate the first nj sets: set 0 is always the one worked on
+          const St t = s0;
+          s0 = s1;
+          s1 = nj > 2 ? s2 : t;
+          s2 = nj > 3 ? s3 : t;
+          s3 = t;
+        }
       }
     }
   }
@@ -890,10 +1032,13 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 typedef void (*kernel_fn)(const Params);
 
 // [0] general / [1] FAST instantiation of the generic-path and table-path kernels
-struct Variant { int A, V; kernel_fn generic[2], table[2]; int entw; };
+// roll[0] / roll[1]: the fused rollout on the generic / table path
+struct Variant { int A, V; kernel_fn generic[2], table[2]; int entw; kernel_fn roll[2]; };
 #define MG_VARIANT_TAB(A, V) {A, V, {mg_kernel<A, V, false, false>, mg_kernel<A, V, false, true>}, \
-                              {mg_kernel<A, V, true, false>, mg_kernel<A, V, true, true>}, ViewGeom<V>::ENTW}
-#define MG_VARIANT_GEN(A, V) {A, V, {mg_kernel<A, V, false, false>, mg_kernel<A, V, false, true>}, {nullptr, nullptr}, 0}
+                              {mg_kernel<A, V, true, false>, mg_kernel<A, V, true, true>}, ViewGeom<V>::ENTW, \
+                              {mg_rollout_kernel<A, V, false>, mg_rollout_kernel<A, V, true>}}
+#define MG_VARIANT_GEN(A, V) {A, V, {mg_kernel<A, V, false, false>, mg_kernel<A, V, false, true>}, {nullptr, nullptr}, 0, \
+                              {mg_rollout_kernel<A, V, false>, nullptr}}
 const Variant kVariants[] = {
     MG_VARIANT_TAB(1, 5), MG_VARIANT_TAB(2, 5), MG_VARIANT_TAB(3, 5), MG_VARIANT_TAB(4, 5), MG_VARIANT_TAB(5, 5), MG_VARIANT_TAB(3, 3),
     MG_VARIANT_GEN(1, 7), MG_VARIANT_GEN(2, 7), MG_VARIANT_GEN(3, 7),
@@ -1120,7 +1265,8 @@ void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* l
 
 int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, const int8_t* respawn,
            const int8_t* reset_spawn, const uint8_t* mask, int random_actions, uint8_t* actions_out,
-           const int8_t* objdrop = nullptr, const int8_t* reset_gen = nullptr, const int8_t* scatter = nullptr) {
+           const int8_t* objdrop = nullptr, const int8_t* reset_gen = nullptr, const int8_t* scatter = nullptr,
+           int n_roll = 0, const mg_rollout_out* roll = nullptr) {
   Params p;
   memset(&p, 0, sizeof(p));
   const mg_config& c = h->cfg;
@@ -1159,6 +1305,25 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     return MG_OK;
   }
   if (objdrop || reset_gen || scatter) return fail(MG_EINVAL, "objdrop / gen / scatter injection needs a mutable-grid handle");
+  if (n_roll > 0) {
+    // Fused rollout: the trajectory is written once and far exceeds the caches, so every image is streamed.  Which path:
+    // the table kernel (persistent, 16 waves per workgroup, its 44 KB table fill now paid once per K steps) whenever the
+    // handle has a table, unless MG_DEBUG_ROLL_PATH forces one (tuning experiments only).
+    bool rt = h->use_table && h->var->roll[1] != nullptr;
+    if (const char* e = debug_env("MG_DEBUG_ROLL_PATH")) rt = rt && atoi(e) == MG_PATH_TABLE;
+    p.n_roll = n_roll;
+    p.traj_obs = roll->obs_image; p.traj_reward = roll->reward; p.traj_dd = roll->dir_done;
+    p.traj_actions = reinterpret_cast<uint32_t*>(roll->actions);
+    p.nt_obs = 0xFF; p.random_actions = 1;
+    launch_geometry(h, rt, &nw, &grid, &lds);
+    if (!rt) {                                   // persistent on the generic path too: up to four chunks per wave, stepped together
+      const int per_cu = std::max(1, std::min((int)((size_t)kLdsLimit / lds), 32 / nw));
+      grid = (unsigned)std::min<int64_t>(grid, (int64_t)h->n_cu * per_cu);
+    }
+    hipLaunchKernelGGL(h->var->roll[rt ? 1 : 0], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
+    HIP_TRY(hipGetLastError());
+    return MG_OK;
+  }
   const bool table = launch_uses_table(h);
   launch_geometry(h, table, &nw, &grid, &lds);
   const int fast = (op == OP_STEP && !order && !respawn && !reset_spawn && !random_actions && !h->buf.env_reward) ? 1 : 0;
@@ -1300,7 +1465,8 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail(MG_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
   for (kernel_fn fn : {var ? var->generic[0] : nullptr, var ? var->generic[1] : nullptr, var ? var->table[0] : nullptr,
-                       var ? var->table[1] : nullptr, dvar ? dvar->fn : nullptr}) {
+                       var ? var->table[1] : nullptr, var ? var->roll[0] : nullptr, var ? var->roll[1] : nullptr,
+                       dvar ? dvar->fn : nullptr}) {
     if (!fn) continue;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
     if (e != hipSuccess) { (void)hipStreamDestroy(h->stream); delete h; return fail(MG_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
@@ -1700,6 +1866,18 @@ int mg_debug_device_sqrt(int device, int32_t n, double* out) {
   (void)hipFree(d);
   if (e != hipSuccess) return fail(MG_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
   return MG_OK;
+}
+
+int mg_rollout_random(mg_handle* h, int32_t n_steps, const mg_rollout_out* out) {
+  if (!h || !out) return fail(MG_EINVAL, "null argument");
+  if (n_steps < 1 || n_steps > 65535) return fail(MG_EINVAL, "n_steps must be in [1,65535]");
+  if (!out->obs_image || !out->reward || !out->dir_done) return fail(MG_EINVAL, "obs_image, reward and dir_done of mg_rollout_out must be set");
+  if (h->dynamic) return fail(MG_EUNSUPPORTED, "mg_rollout_random runs the shared-map kernels (static layouts of empty/wall/goal/lava cells)");
+  if (h->buf.env_reward) return fail(MG_EUNSUPPORTED, "mg_rollout_random has no env_reward output (emit_env_reward = 0)");
+  if (!h->have_reset) return fail(MG_ESTATE, "mg_reset must be called before mg_rollout_random");
+  int rc = launch(h, OP_STEP, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, n_steps, out);
+  if (rc == MG_OK) h->t += (uint64_t)n_steps;
+  return rc;
 }
 
 int mg_get_buffers(mg_handle* h, mg_buffers* out) {

@@ -53,6 +53,10 @@ class MgBuffers(C.Structure):
   ]
 
 
+class MgRolloutOut(C.Structure):
+  _fields_ = [('obs_image', C.c_void_p), ('reward', C.c_void_p), ('dir_done', C.c_void_p), ('actions', C.c_void_p)]
+
+
 # name -> (restype, argtypes): every symbol include/mgrid.h declares
 SYMBOLS = {
     'mg_create': (C.c_int, [C.POINTER(MgConfig), C.c_int, C.POINTER(C.c_void_p)]),
@@ -68,6 +72,7 @@ SYMBOLS = {
     'mg_reset_inject_scatter': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mg_export_grid': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_step_random': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mg_rollout_random': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(MgRolloutOut)]),
     'mg_get_buffers': (C.c_int, [C.c_void_p, C.POINTER(MgBuffers)]),
     'mg_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_get_stream': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

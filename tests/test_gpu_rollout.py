@@ -1,0 +1,118 @@
+"""mg_rollout_random — K fused free-running steps with on-device random actions in one launch — against (a) the CPU
+oracle stepping K times with its own Philox action draw, slot by slot, and (b) a twin handle that takes the same K steps
+one mg_step_random launch at a time.  Bit-exact: trajectory obs / dir / done / f64 rewards / actions, and afterwards the
+handle's own buffers, env_state and step index."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle  # noqa: E402
+
+
+def _need_gpu():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+
+
+@pytest.mark.parametrize('path', ['generic', 'table'])
+@pytest.mark.parametrize('n,K,calls', [(1000, 7, 3), (4096, 37, 3), (64, 130, 1), (70000, 3, 2)])
+def test_rollout_matches_oracle_and_single_steps(cluttered_cells, monkeypatch, path, n, K, calls):
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  monkeypatch.setenv('MG_DEBUG_ROLL_PATH', {'generic': '1', 'table': '2'}[path])
+  kp = 'table' if path == 'table' else 'auto'
+  seed = n + K
+  env = BatchedMultiGrid(cluttered_cells, n_envs=n, seed=seed, kernel_path=kp)
+  twin = BatchedMultiGrid(cluttered_cells, n_envs=n, seed=seed, kernel_path=kp)
+  orc = c_oracle.OracleBatch(cluttered_cells, n, shaping=1, auto_reset=1, seed=seed) if n <= 4096 else None
+  env.reset()
+  twin.reset()
+  if orc is not None:
+    orc.reset()
+  traj = None
+  touches = 0
+  for call in range(calls):
+    traj = env.rollout_random(K, out=traj)
+    assert env.step_index == (call + 1) * K
+    img = traj['image'].cpu().numpy().reshape(K, 3, n, -1)
+    rew = traj['reward'].cpu().numpy()
+    dirs = traj['direction'].cpu().numpy()
+    done = traj['done'].cpu().numpy()
+    acts = traj['actions'].cpu().numpy()
+    for k in range(K):
+      w = 'call %d step %d' % (call, k)
+      act_out = torch.zeros((twin.stride, twin.slots), dtype=torch.uint8, device=twin.device)
+      twin.step_random(act_out)
+      assert np.array_equal(img[k], twin.obs_image.cpu().numpy().reshape(3, n, -1)), w + ' obs vs single steps'
+      assert np.array_equal(rew[k].view(np.int64), twin.reward.cpu().numpy().view(np.int64)), w + ' reward vs single steps'
+      assert np.array_equal(dirs[k], twin.obs_dir.cpu().numpy()) and np.array_equal(done[k], twin.done.cpu().numpy()), w
+      assert np.array_equal(acts[k], act_out[:n, :3].cpu().numpy()), w + ' actions'
+      if orc is not None:
+        orc.step(None)
+        assert np.array_equal(img[k], orc.obs_image[:, :n]), w + ' obs vs oracle'
+        assert np.array_equal(rew[k].view(np.int64), orc.reward[:, :n].view(np.int64)), w + ' reward vs oracle'
+        assert np.array_equal(dirs[k], orc.obs_dir[:, :n]) and np.array_equal(done[k], orc.done[:n]), w + ' dir/done vs oracle'
+      touches += int((rew[k] >= 4.5).sum())
+    # the handle is where K single steps leave it
+    assert torch.equal(env._env_state[:n], twin._env_state[:n])
+    assert torch.equal(env._obs_image[:, :n], twin._obs_image[:, :n])
+    assert torch.equal(env._reward[:, :n].view(torch.int64), twin._reward[:, :n].view(torch.int64))
+    assert torch.equal(env._dir_done[:n, :4], twin._dir_done[:n, :4])
+    if orc is not None:
+      assert np.array_equal(env.agent_state.cpu().numpy().view(np.uint32), orc.agent_state()[:, :n])
+  assert env.check_errors() == 0 and twin.check_errors() == 0
+  if n >= 1000 and K * calls >= 20:
+    assert touches > 0
+  env.close()
+  twin.close()
+
+
+def test_rollout_other_shapes(cluttered_cells, empty_cells):
+  """Other (n_agents, view) instantiations, no shaping / no auto-reset, ragged n."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  for A, V, kw in ((1, 5, {}), (2, 7, dict(shaping=None)), (5, 5, dict(auto_reset=False)), (4, 5, dict(shaping='v7'))):
+    n, K = 333, 45
+    env = BatchedMultiGrid(cluttered_cells, n_envs=n, n_agents=A, view_size=V, max_steps=30, seed=A * V, **kw)
+    orc = c_oracle.OracleBatch(cluttered_cells, n, A=A, V=V, max_steps=30, shaping={'v8': 1, None: 0, 'v7': 2}[kw.get('shaping', 'v8')],
+                               auto_reset=int(kw.get('auto_reset', True)), seed=A * V)
+    env.reset()
+    orc.reset()
+    traj = env.rollout_random(K)
+    img = traj['image'].cpu().numpy().reshape(K, A, n, -1)
+    rew = traj['reward'].cpu().numpy()
+    done = traj['done'].cpu().numpy()
+    for k in range(K):
+      orc.step(None)
+      assert np.array_equal(img[k], orc.obs_image[:, :n]), (A, V, k)
+      assert np.array_equal(rew[k].view(np.int64), orc.reward[:, :n].view(np.int64)), (A, V, k)
+      assert np.array_equal(done[k], orc.done[:n]), (A, V, k)
+    assert np.array_equal(env.agent_state.cpu().numpy().view(np.uint32), orc.agent_state()[:, :n])
+    assert env.check_errors() == 0
+    env.close()
+
+
+def test_rollout_refusals(cluttered_cells, playground_cells):
+  _need_gpu()
+  from multigrid_amd import lib
+  from multigrid_amd.batched import BatchedMultiGrid
+  env = BatchedMultiGrid(cluttered_cells, n_envs=64)
+  with pytest.raises(lib.MgError, match='mg_reset'):
+    env.rollout_random(4)
+  env.reset()
+  with pytest.raises(lib.MgError, match='n_steps'):
+    env.rollout_random(0)
+  env.close()
+  env = BatchedMultiGrid(playground_cells, n_envs=64)
+  env.reset()
+  with pytest.raises(lib.MgError, match='shared-map'):
+    env.rollout_random(4)
+  env.close()
+  env = BatchedMultiGrid(cluttered_cells, n_envs=64, emit_env_reward=True)
+  env.reset()
+  with pytest.raises(lib.MgError, match='env_reward'):
+    env.rollout_random(4)
+  env.close()

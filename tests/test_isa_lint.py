@@ -38,3 +38,64 @@ _Zkernel:
 '''
   k, n, v = lint.lint(text)
   assert k == 1 and n == 1 and len(v) == 1 and 'v[5]' in v[0]
+
+
+def test_lint_follows_the_control_flow_graph():
+  """A wait inside a conditionally executed block must not clear the in-flight set for the code after the block."""
+  import isa_prefetch_lint as lint
+  text = '''
+_Zkernel:
+	;;#ASMSTART
+	global_load_dword v5, v[2:3], off
+	;;#ASMEND
+	s_cbranch_scc0 .LBB0_2
+	s_waitcnt vmcnt(0)
+	v_mov_b32_e32 v9, 0
+.LBB0_2:
+	v_add_u32_e32 v7, v5, v6
+	s_endpgm
+'''
+  k, n, v = lint.lint(text)
+  assert k == 1 and n == 1 and len(v) == 1 and 'v[5]' in v[0]
+  # the same code with the wait on every path is clean
+  k, n, v = lint.lint(text.replace('	s_cbranch_scc0 .LBB0_2\n', ''))
+  assert v == []
+
+
+def test_lint_counts_the_stores_on_every_path_to_a_counted_wait():
+  import isa_prefetch_lint as lint
+  text = '''
+_Zkernel:
+	;;#ASMSTART
+	global_load_dword v5, v[2:3], off
+	;;#ASMEND
+	global_store_dword v[10:11], v12, off
+	s_cbranch_execz .LBB0_2
+	global_store_dword v[10:11], v12, off
+.LBB0_2:
+	;;#ASMSTART
+	s_waitcnt vmcnt(2)
+	;;#ASMEND
+	v_add_u32_e32 v7, v5, v6
+	s_endpgm
+'''
+  k, n, v = lint.lint(text)
+  assert len(v) == 1 and 'vmcnt(2)' in v[0] and 'only 1' in v[0]
+  assert lint.lint(text.replace('vmcnt(2)', 'vmcnt(1)'))[2] == []
+  # loops: the count is the minimum over all paths, back edges included
+  loop = '''
+_Zkernel:
+.LBB0_1:
+	;;#ASMSTART
+	global_load_dword v5, v[2:3], off
+	;;#ASMEND
+	global_store_dword v[10:11], v12, off
+	global_store_dword v[10:11], v12, off
+	;;#ASMSTART
+	s_waitcnt vmcnt(2)
+	;;#ASMEND
+	v_add_u32_e32 v7, v5, v6
+	s_cbranch_scc1 .LBB0_1
+	s_endpgm
+'''
+  assert lint.lint(loop)[2] == []
