@@ -37,7 +37,8 @@ _Zkernel:
 	s_endpgm
 '''
   k, n, v = lint.lint(text)
-  assert k == 1 and n == 1 and len(v) == 1 and 'v[5]' in v[0]
+  # the touch of the in-flight register, and the counted wait that no store precedes
+  assert k == 1 and n == 1 and len(v) == 2 and 'v[5]' in v[0] and 'vmcnt(3)' in v[1]
 
 
 def test_lint_follows_the_control_flow_graph():
