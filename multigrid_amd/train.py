@@ -28,6 +28,8 @@ def main(argv=None):
   ap.add_argument('--window', type=int, default=10)
   ap.add_argument('--out', default='models8/best_performance')
   ap.add_argument('--no-graph', action='store_true')
+  ap.add_argument('--policy', default='simple', choices=['simple', 'multigrid_net'],
+                  help="simple = v8's SimplePPOAgent per agent; multigrid_net = networks/multigrid_network.py per agent (+ value head)")
   args = ap.parse_args(argv)
 
   import torch
@@ -45,13 +47,13 @@ def main(argv=None):
   env = multigrid_amd.make_batched(args.env_id, n, device=local_rank, seed=args.seed, env_id_base=base,
                                    shaping='v8', auto_reset=True)
   env.reset()
-  ctl = ppo.BatchedController(env, lr=args.lr, seed=args.seed)
+  ctl = ppo.BatchedController(env, lr=args.lr, seed=args.seed, policy=args.policy)
   window, best = [], float('-inf')
   t0 = time.time()
   for it in range(args.iters):
     ctl.stats.totals.zero_()
     traj = ctl.rollout(args.steps, use_graph=not args.no_graph)
-    ctl.stats.add(torch.stack(traj['reward'], dim=1), traj['done'])
+    ctl.stats.add(traj['reward'], traj['done'])
     losses = ctl.update(traj)
     st = ctl.stats.reduce()
     window = (window + [st['mean_collective_return']])[-args.window:]
