@@ -55,6 +55,10 @@ extern "C" {
 #define MG_SHAPING_V8   1   /* reward = v8_robust_ppo.py:171-220 shaped reward */
 #define MG_SHAPING_V7   2   /* reward = v7_stable_goal_focused_ppo.py:60-108 shaped reward (StableRewardShaper) */
 
+/* reward_dtype */
+#define MG_REWARD_F64 0
+#define MG_REWARD_F32 1
+
 /* kernel_path: how the static part of an agent's view is produced.  TABLE = precomputed once
  * per (free cell, dir) on the host and kept in LDS; GENERIC = slice/rotate/process_vis evaluated
  * per step from the LDS map.  Both give identical bytes.  AUTO: GENERIC below 65,536 envs (no table fill), TABLE with
@@ -150,7 +154,9 @@ typedef struct mg_config {
   int32_t gen_n_goals;       /* CLUTTERED: 1 = randomize_goal (cluttered.py:28-31); MEETUP: n_goals (meetup.py:32) */
   int32_t gen_n_clutter;     /* n_clutter (cluttered.py:16, meetup.py:33) */
   int32_t gen_flags;         /* MG_GEN_* */
-  int32_t reserved1;
+  int32_t reward_dtype;      /* MG_REWARD_F64 (0, default: the reference's Python floats) or MG_REWARD_F32: the reward buffers
+                                hold float — the cast v8 applies before its update, torch.FloatTensor(rewards), v8_robust_ppo.py:311 —
+                                12 bytes less to write per env-step with three agents.  Not with emit_env_reward. */
 } mg_config;
 
 typedef struct mg_buffers {
@@ -160,12 +166,13 @@ typedef struct mg_buffers {
   int32_t  obs_cell_bytes; /* V*V*3 : bytes of one agent's image, [vx][vy][(type,color,state)]
                               exactly as Grid.encode lays it out */
   uint8_t* obs_image;    /* [A][env_stride][V*V*3]  — obs['image'][a]   */
-  double*  reward;       /* [A][env_stride]  rewards[a] (shaped when shaping_kind != NONE) */
+  double*  reward;       /* [A][env_stride]  rewards[a] (shaped when shaping_kind != NONE); float[A][env_stride] behind the same
+                            pointer when reward_dtype = MG_REWARD_F32 (reward_elem_bytes = 4) */
   double*  env_reward;   /* [A][env_stride]  unshaped env reward, NULL unless emit_env_reward */
   uint8_t* dir_done;     /* [env_stride][dir_done_bytes]: byte a = obs['direction'][a] (a < A), byte A =
                             collective done of the step just taken; dir_done_bytes = 4 (A <= 3) or 8 */
   int32_t  dir_done_bytes;
-  int32_t  reserved;
+  int32_t  reward_elem_bytes;   /* 8, or 4 with MG_REWARD_F32 */
   uint32_t* env_state;   /* [env_stride][A+1]: words 0..A-1 = one word per agent
                               x:6 | y:6<<6 | dir:2<<12 | prev_x:6<<14 | prev_y:6<<20 | valid<<26 | stationary:3<<27
                             (post-step, post-respawn position = what v8 reads as env.agent_pos[a], v8:242;
@@ -229,7 +236,10 @@ int mg_set_fixed_spawn(mg_handle* h, const int8_t* xy, int mode);
 /* env.reset() (multigrid.py:466-501) for every env whose mask byte is non-zero (mask = device
  * pointer uint8[n_envs], or NULL for all).  Spawns are drawn on device (Philox) with the
  * reference's distribution: uniform rejection sampling over the grid for an empty cell not
- * holding an agent, then uniform direction (multigrid.py:598-619, 665-666).  Writes obs. */
+ * holding an agent, then uniform direction (multigrid.py:598-619, 665-666).  Writes obs.
+ * Every explicit reset call draws afresh (Philox counter word = bit 63 | number of mg_reset* calls on the handle so far):
+ * reset(); reset() gives new spawns / layouts, as the reference's clock-seeded place_agent does (cluttered.py:55-63), and
+ * an explicit reset never repeats the draws of the auto-reset inside a step. */
 int mg_reset(mg_handle* h, const uint8_t* env_mask);
 
 /* Same, with the spawn the reference's time-seeded RNG would have produced injected:

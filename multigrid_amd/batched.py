@@ -34,7 +34,7 @@ class BatchedMultiGrid:
                competitive=False, shaping='v8', auto_reset=True, device=0, seed=0,
                env_id_base=0, emit_env_reward=False, use_torch_stream=True, kernel_path='auto',
                kind='static', size=None, n_goals=0, n_clutter=0, walls_are_lava=False, two_rooms=False, fixed_spawn=None,
-               fixed_mode='always'):
+               fixed_mode='always', reward_dtype='f64'):
     """kind='static': `cells` uint8[H, W, 3] is the layout every reset starts from (objects allowed).
     kind='doorkey' | 'cluttered' | 'meetup': `cells` is None and `size` the grid size; layouts are drawn
     on device per env and per reset.  cluttered: n_goals = 1 for randomize_goal (0: goal at (size-2, size-2)),
@@ -61,7 +61,7 @@ class BatchedMultiGrid:
         env_kind=_lib.KINDS[kind], emit_env_reward=int(emit_env_reward),
         gen_n_goals=int(n_goals), gen_n_clutter=int(n_clutter), gen_flags=(_lib.GEN_LAVAWALL if walls_are_lava == 'lavawall' else _lib.GEN_LAVA if walls_are_lava else 0)
         | (_lib.GEN_TWO_ROOMS if two_rooms else 0),
-        kernel_path={'auto': 0, 'generic': 1, 'table': 2}[kernel_path],
+        kernel_path={'auto': 0, 'generic': 1, 'table': 2}[kernel_path], reward_dtype={'f64': 0, 'f32': 1}[reward_dtype],
         n_envs=n_envs, env_id_base=env_id_base, seed=seed)
     self.h = C.c_void_p()
     _lib.check(self.L.mg_create(C.byref(cfg), self.device_index, C.byref(self.h)))
@@ -84,7 +84,7 @@ class BatchedMultiGrid:
     self._obs_image = _alias(b.obs_image, (A, S, V, V, 3), '|u1', dev) if b.obs_image else None
     self._obs_full = _alias(b.obs_full, (S, self.width, self.height, 3), '|u1', dev) if b.obs_full else None
     self._dir_done = _alias(b.dir_done, (S, int(b.dir_done_bytes)), '|u1', dev)
-    self._reward = _alias(b.reward, (A, S), '<f8', dev)
+    self._reward = _alias(b.reward, (A, S), '<f8' if int(b.reward_elem_bytes) == 8 else '<f4', dev)
     self._env_reward = _alias(b.env_reward, (A, S), '<f8', dev) if b.env_reward else None
     self._env_state = _alias(b.env_state, (S, A + 1), '<i4', dev)
     # ... and the [:, :n_envs] views callers use
@@ -274,7 +274,7 @@ class BatchedMultiGrid:
     if out is None or out['_K'] != K:
       ddb = self._dir_done.shape[1]
       out = {'_K': K, '_obs': torch.empty((K, A, S, V, V, 3), dtype=torch.uint8, device=dev),
-             '_reward': torch.empty((K, A, S), dtype=torch.float64, device=dev),
+             '_reward': torch.empty((K, A, S), dtype=self._reward.dtype, device=dev),
              '_dd': torch.empty((K, S, ddb), dtype=torch.uint8, device=dev),
              '_act': torch.empty((K, S, self.slots), dtype=torch.uint8, device=dev) if store_actions else None}
       out.update(image=out['_obs'][:, :, :n], reward=out['_reward'][:, :, :n], direction=out['_dd'][:, :n, :A].permute(0, 2, 1),

@@ -524,7 +524,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 #pragma unroll
       for (int a = 0; a < A; ++a) {
         const int64_t i = (int64_t)a * p.stride + n;
-        p.reward[i] = out_rew[a];
+        if (p.reward_f32) reinterpret_cast<float*>(p.reward)[i] = (float)out_rew[a]; else p.reward[i] = out_rew[a];
         if (p.env_reward) p.env_reward[i] = rew[a];
       }
     }

@@ -104,7 +104,7 @@ struct Params {
   uint32_t* aux;               // [stride][4]  MEETUP goal positions + past distances
   uint8_t* obs_full;           // [stride][W*H*3]  fully observed obs
   // fused K-step rollout (mg_rollout_random): step k of the launch writes slot k of the caller's trajectory buffers
-  int32_t n_roll, roll_pad;
+  int32_t n_roll, reward_f32;  // reward_f32: the reward buffers hold float, not double (mg_config.reward_dtype)
   uint8_t* traj_obs;           // [K][A][stride][V*V*3]
   double* traj_reward;         // [K][A][stride]
   uint8_t* traj_dd;            // [K][stride][dd_bytes]
@@ -670,8 +670,15 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
 #pragma unroll
       for (int a = 0; a < A; ++a) {
         const int64_t i = (int64_t)a * p.stride + n;
-        if (ROLL) __builtin_nontemporal_store(out_rew[a], p.reward + i); else p.reward[i] = out_rew[a];
-        if (ROLL && reward2) reward2[i] = out_rew[a];
+        if (p.reward_f32) {                                   // torch.FloatTensor(rewards) (v8:311), done at the source
+          const float r32 = (float)out_rew[a];
+          if (ROLL) __builtin_nontemporal_store(r32, reinterpret_cast<float*>(p.reward) + i);
+          else reinterpret_cast<float*>(p.reward)[i] = r32;
+          if (ROLL && reward2) reinterpret_cast<float*>(reward2)[i] = r32;
+        } else {
+          if (ROLL) __builtin_nontemporal_store(out_rew[a], p.reward + i); else p.reward[i] = out_rew[a];
+          if (ROLL && reward2) reward2[i] = out_rew[a];
+        }
         if (!FAST && p.env_reward) p.env_reward[i] = rew[a];
       }
     }
@@ -941,7 +948,7 @@ __global__ __launch_bounds__(kMaxBlock) void mg_rollout_kernel(const Params p) {
       const bool last = k == p.n_roll - 1;
       q.t = p.t + (uint64_t)k;
       q.obs_image = p.traj_obs + k * slot_obs;
-      q.reward = p.traj_reward + k * slot_rew;
+      q.reward = reinterpret_cast<double*>(reinterpret_cast<char*>(p.traj_reward) + k * slot_rew * (p.reward_f32 ? 4 : 8));
       q.dir_done = p.traj_dd + k * slot_dd;
       q.actions_out = p.traj_actions ? p.traj_actions + k * slot_act : nullptr;
 #pragma unroll 1
@@ -1120,6 +1127,7 @@ struct mg_handle {
   int PW, PH, n_cu, dd_bytes;
   bool have_map, have_reset;
   uint64_t t;
+  uint64_t reset_epoch;  // explicit mg_reset* calls so far
   int gx, gy;
   // device memory
   uint32_t* map_pad;
@@ -1275,7 +1283,9 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   p.shaping = c.shaping_kind; p.auto_reset = c.auto_reset; p.dd_bytes = h->dd_bytes;
   p.op = op; p.random_actions = random_actions; p.PW = h->PW; p.PH = h->PH; p.n_entries = h->n_entries;
   p.n_envs = c.n_envs; p.stride = h->stride; p.n_chunks = h->n_chunks;
-  p.gid_base = (uint64_t)c.env_id_base; p.t = h->t;
+  // explicit resets draw under their own counter word — bit 63 + the number of resets so far — so that reset(); reset()
+  // redraws (the reference reseeds from the clock, cluttered.py:55-63) and shares nothing with the auto-reset inside step t
+  p.gid_base = (uint64_t)c.env_id_base; p.t = op == OP_RESET ? ((1ull << 63) | h->reset_epoch) : h->t;
   p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32);
   p.map_pad = h->map_pad; p.dist_lut = h->dist_lut;
   p.view_table = h->view_table; p.cell_index = h->cell_index;
@@ -1295,6 +1305,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   p.fixed_mode = h->fixed_mode; p.fixed_pd = h->fixed_pd; p.fixed_pd_hi = h->fixed_pd_hi; p.reserved_pd = 0;
   p.scatter = reinterpret_cast<const uint16_t*>(scatter); p.aux = h->aux; p.obs_full = h->obs_full;
   p.nt_obs = launch_streams_obs(h);
+  p.reward_f32 = c.reward_dtype == MG_REWARD_F32 ? 1 : 0;
   int nw; unsigned grid; size_t lds;
   DeviceGuard g(h->device);
   if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
@@ -1302,6 +1313,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     dyn_geometry(h, &nw, &grid, &lds);
     hipLaunchKernelGGL(h->dvar->fn, dim3(grid), dim3(nw * kWave), lds, h->stream, p);
     HIP_TRY(hipGetLastError());
+    if (op == OP_RESET) h->reset_epoch += 1;
     return MG_OK;
   }
   if (objdrop || reset_gen || scatter) return fail(MG_EINVAL, "objdrop / gen / scatter injection needs a mutable-grid handle");
@@ -1329,6 +1341,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   const int fast = (op == OP_STEP && !order && !respawn && !reset_spawn && !random_actions && !h->buf.env_reward) ? 1 : 0;
   hipLaunchKernelGGL(table ? h->var->table[fast] : h->var->generic[fast], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
   HIP_TRY(hipGetLastError());
+  if (op == OP_RESET) h->reset_epoch += 1;
   return MG_OK;
 }
 
@@ -1392,6 +1405,8 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (c.max_steps < 1 || c.max_steps > 65534) return fail(MG_EINVAL, "max_steps must be in [1,65534]");
   if (c.shaping_kind < MG_SHAPING_NONE || c.shaping_kind > MG_SHAPING_V7) return fail(MG_EINVAL, "unknown shaping_kind");
   if (c.kernel_path < MG_PATH_AUTO || c.kernel_path > MG_PATH_TABLE) return fail(MG_EINVAL, "unknown kernel_path");
+  if (c.reward_dtype != MG_REWARD_F64 && c.reward_dtype != MG_REWARD_F32) return fail(MG_EINVAL, "unknown reward_dtype");
+  if (c.reward_dtype == MG_REWARD_F32 && c.emit_env_reward) return fail(MG_EUNSUPPORTED, "env_reward is a float64 output: reward_dtype must be MG_REWARD_F64 with emit_env_reward");
   if (c.env_id_base < 0 || (uint64_t)c.env_id_base + (uint64_t)c.n_envs > 0xFFFFFFFFull)
     return fail(MG_EINVAL, "global env ids must fit 32 bits");
   if (c.env_kind < MG_KIND_STATIC || c.env_kind > MG_KIND_FOURROOMS) return fail(MG_EINVAL, "unknown env_kind");
@@ -1438,7 +1453,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
 
   (void)noalloc_warm(device);   // mg_step_noalloc's per-device set-up, so that its own calls find it done (a failure is reported there)
   mg_handle* h = new mg_handle();
-  h->cfg = c; h->device = device; h->var = var; h->t = 0; h->have_map = h->have_reset = false;
+  h->cfg = c; h->device = device; h->var = var; h->t = 0; h->reset_epoch = 0; h->have_map = h->have_reset = false;
   h->dynamic = false; h->dvar = dvar; h->GW = (c.width * c.height + 3) / 4;
   h->base_grid = nullptr; h->carry = nullptr; h->grid = nullptr; h->aux = nullptr; h->obs_full = nullptr;
   h->full_obs = c.env_kind == MG_KIND_MEETUP; h->LW = c.width; h->LH = c.height;
@@ -1496,6 +1511,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   }
   h->buf.n_envs = c.n_envs; h->buf.env_stride = h->stride; h->buf.n_agents = c.n_agents; h->buf.obs_cell_bytes = rowb;
   h->buf.dir_done_bytes = h->dd_bytes;
+  h->buf.reward_elem_bytes = c.reward_dtype == MG_REWARD_F32 ? 4 : 8;
   h->buf.aux = h->aux; h->buf.obs_full = h->obs_full;
   h->buf.obs_full_bytes = h->full_obs ? c.width * c.height * 3 : 0;
   if (c.env_kind != MG_KIND_STATIC) {
@@ -1803,6 +1819,7 @@ int mg_step_noalloc(const mg_config* cfg, int device, void* hip_stream, uint64_t
   if (c.n_envs < 1) return fail(MG_EINVAL, "n_envs must be >= 1");
   if (c.max_steps < 1 || c.max_steps > 65534) return fail(MG_EINVAL, "max_steps must be in [1,65534]");
   if (c.shaping_kind < MG_SHAPING_NONE || c.shaping_kind > MG_SHAPING_V7) return fail(MG_EINVAL, "unknown shaping_kind");
+  if (c.reward_dtype != MG_REWARD_F64 && c.reward_dtype != MG_REWARD_F32) return fail(MG_EINVAL, "unknown reward_dtype");
   if (c.env_id_base < 0 || (uint64_t)c.env_id_base + (uint64_t)c.n_envs > 0xFFFFFFFFull)
     return fail(MG_EINVAL, "global env ids must fit 32 bits");
   const Variant* var = nullptr;
@@ -1846,6 +1863,7 @@ int mg_step_noalloc(const mg_config* cfg, int device, void* hip_stream, uint64_t
   p.actions = reinterpret_cast<const uint32_t*>(actions);
   p.obs_image = obs_image; p.reward = reward; p.dir_done = dir_done; p.env_state = env_state; p.err = err;
   p.nt_obs = hh.n_chunks > (int64_t)d.n_cu * 16 * kUpfront ? 0xFF : 0;
+  p.reward_f32 = c.reward_dtype == MG_REWARD_F32 ? 1 : 0;
   int nw; unsigned grid; size_t lds;
   launch_geometry(&hh, false, &nw, &grid, &lds);
   hipLaunchKernelGGL(var->generic[1], dim3(grid), dim3(nw * kWave), lds, stream, p);

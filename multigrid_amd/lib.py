@@ -39,7 +39,7 @@ class MgConfig(C.Structure):
       ('shaping_kind', C.c_int32), ('auto_reset', C.c_int32), ('env_kind', C.c_int32),
       ('emit_env_reward', C.c_int32), ('kernel_path', C.c_int32),
       ('n_envs', C.c_int64), ('env_id_base', C.c_int64), ('seed', C.c_uint64),
-      ('gen_n_goals', C.c_int32), ('gen_n_clutter', C.c_int32), ('gen_flags', C.c_int32), ('reserved1', C.c_int32),
+      ('gen_n_goals', C.c_int32), ('gen_n_clutter', C.c_int32), ('gen_flags', C.c_int32), ('reward_dtype', C.c_int32),
   ]
 
 
@@ -47,7 +47,7 @@ class MgBuffers(C.Structure):
   _fields_ = [
       ('n_envs', C.c_int64), ('env_stride', C.c_int64), ('n_agents', C.c_int32), ('obs_cell_bytes', C.c_int32),
       ('obs_image', C.c_void_p), ('reward', C.c_void_p), ('env_reward', C.c_void_p), ('dir_done', C.c_void_p),
-      ('dir_done_bytes', C.c_int32), ('reserved', C.c_int32), ('env_state', C.c_void_p),
+      ('dir_done_bytes', C.c_int32), ('reward_elem_bytes', C.c_int32), ('env_state', C.c_void_p),
       ('carry', C.c_void_p), ('grid', C.c_void_p), ('grid_words', C.c_int32), ('mutable_grid', C.c_int32),
       ('aux', C.c_void_p), ('obs_full', C.c_void_p), ('obs_full_bytes', C.c_int32), ('reserved2', C.c_int32),
   ]

@@ -98,6 +98,7 @@ KIND_STATIC, KIND_DOORKEY, KIND_CLUTTERED, KIND_MEETUP, KIND_FOURROOMS = 0, 1, 2
 KINDS = {'static': KIND_STATIC, 'doorkey': KIND_DOORKEY, 'cluttered': KIND_CLUTTERED, 'meetup': KIND_MEETUP,
          'fourrooms': KIND_FOURROOMS}
 MAXOBJ = 64
+RESET_EPOCH_BIT = 1 << 63   # counter word of explicit resets: this bit + the handle's reset count (see OracleEnv._reset_t)
 
 
 FIXED_ALWAYS, FIXED_AT_RESET = 1, 2     # mgo_set_fixed_spawn modes (EmptyEnv fixed start / MazeEnv)
@@ -175,6 +176,7 @@ class OracleEnv:
       cells = np.ascontiguousarray(cells, dtype=np.uint8).reshape(W * H * 3)
       self.L.mgo_set_map(self.h, _p(cells, u8p))
     self.t = 0
+    self.reset_epoch = 0
 
   def __del__(self):
     if getattr(self, 'h', None):
@@ -196,11 +198,19 @@ class OracleEnv:
       sp[:, :3] = np.asarray(spawn, np.int8)
     if self.n_obj or scatter is not None:
       sc = None if scatter is None else np.ascontiguousarray(scatter, np.int8).reshape(self.n_obj, 2)
-      self.L.mgo_reset_scatter(self.h, _p(sp, i8p), _p(sc, i8p), self.t)
+      self.L.mgo_reset_scatter(self.h, _p(sp, i8p), _p(sc, i8p), self._reset_t())
       return self._obs()
     g = None if gen is None else np.asarray(gen, np.int8).reshape(4)
-    self.L.mgo_reset_gen(self.h, _p(sp, i8p), _p(g, i8p), self.t)
+    self.L.mgo_reset_gen(self.h, _p(sp, i8p), _p(g, i8p), self._reset_t())
     return self._obs()
+
+  def _reset_t(self):
+    """Counter word of an explicit reset's draws: bit 63 set + the number of explicit resets so far (libmgrid keys
+    them the same way), so that two resets in a row redraw, as the reference's do, and never share a draw with the
+    auto-reset inside step t."""
+    t = RESET_EPOCH_BIT | self.reset_epoch
+    self.reset_epoch += 1
+    return t
 
   def last_scatter(self):
     out = np.zeros((MAXOBJ, 2), np.int8)
@@ -321,6 +331,7 @@ class OracleBatch:
     self.env_reward = np.zeros((A, s), np.float64)
     self.done = np.zeros(s, np.uint8)
     self.t = 0
+    self.reset_epoch = 0
 
   def __del__(self):
     for i in range(getattr(self, 'n', 0)):
@@ -333,13 +344,15 @@ class OracleBatch:
     scatter int8[stride,n_obj,2] = accepted positions of the scattered objects (scatter kinds)."""
     m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
     sp = None if spawn is None else np.ascontiguousarray(spawn, np.int8)
+    t_reset = RESET_EPOCH_BIT | self.reset_epoch           # as OracleEnv._reset_t
+    self.reset_epoch += 1
     if self.n_obj:
       sc = None if scatter is None else np.ascontiguousarray(scatter, np.int8)
       self.L.mgo_batch_reset_scatter(self.envs, self.n, self.stride, _p(m, u8p), _p(sp, i8p), _p(sc, i8p), self.n_obj,
-                                     self.t, _p(self.obs_image, u8p), _p(self.obs_dir, u8p))
+                                     t_reset, _p(self.obs_image, u8p), _p(self.obs_dir, u8p))
       return
     g = None if gen is None else np.ascontiguousarray(gen, np.int8)
-    self.L.mgo_batch_reset_ex(self.envs, self.n, self.stride, _p(m, u8p), _p(sp, i8p), _p(g, i8p), self.t,
+    self.L.mgo_batch_reset_ex(self.envs, self.n, self.stride, _p(m, u8p), _p(sp, i8p), _p(g, i8p), t_reset,
                               _p(self.obs_image, u8p), _p(self.obs_dir, u8p))
 
   def step(self, actions=None, order=None, respawn=None, reset_spawn=None, actions_out=None, objdrop=None,

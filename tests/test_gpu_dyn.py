@@ -230,6 +230,7 @@ def test_static_map_switches_back_to_shared_kernel(cluttered_cells):
     env.step_random()
   orc = c_oracle.OracleBatch(cluttered_cells, 200, shaping=1, auto_reset=1, seed=3)
   env.step_index = 0
+  orc.reset_epoch = 1            # the handle's second explicit reset: explicit resets draw under their own call count
   env.reset()
   orc.reset()
   for t in range(30):

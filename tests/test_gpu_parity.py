@@ -440,6 +440,64 @@ def test_refcompat_env_contract():
   env.close()
 
 
+def test_float32_reward_output(cluttered_cells):
+  """reward_dtype='f32': the reward buffer holds torch.FloatTensor(rewards) (the cast of v8_robust_ppo.py:311) — the float64
+  reward of the twin handle rounded once to float32 — on the step kernels, the fused rollout and the mutable-grid kernel."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  n = 3000
+  a = BatchedMultiGrid(cluttered_cells, n_envs=n, seed=12, reward_dtype='f32')
+  b = BatchedMultiGrid(cluttered_cells, n_envs=n, seed=12)
+  assert a.reward.dtype == torch.float32 and b.reward.dtype == torch.float64
+  a.reset(); b.reset()
+  seen = set()
+  for t in range(120):
+    a.step_random(); b.step_random()
+    assert torch.equal(a.reward, b.reward.float()), t
+    assert torch.equal(a.obs_image, b.obs_image)
+    seen |= set(torch.unique(a.reward).tolist()[:8])
+  assert len(seen) > 4
+  ta, tb = a.rollout_random(9), b.rollout_random(9)
+  assert ta['reward'].dtype == torch.float32 and torch.equal(ta['reward'], tb['reward'].float())
+  assert torch.equal(a.reward, b.reward.float()) and torch.equal(ta['image'], tb['image'])
+  a.close(); b.close()
+  a = BatchedMultiGrid(None, n_envs=500, kind='doorkey', size=6, n_agents=2, view_size=7, max_steps=30, seed=3, reward_dtype='f32')
+  b = BatchedMultiGrid(None, n_envs=500, kind='doorkey', size=6, n_agents=2, view_size=7, max_steps=30, seed=3)
+  a.reset(); b.reset()
+  for t in range(70):
+    a.step_random(); b.step_random()
+    assert torch.equal(a.reward, b.reward.float()), t
+  with pytest.raises(Exception, match='reward_dtype'):
+    BatchedMultiGrid(cluttered_cells, n_envs=64, reward_dtype='f32', emit_env_reward=True)
+  a.close(); b.close()
+
+
+def test_two_resets_in_a_row_redraw(cluttered_cells):
+  """reset(); reset() must not reproduce the same spawns (the reference redraws on every reset, multigrid.py:466-501 /
+  cluttered.py:55-63), an explicit reset must not repeat the auto-reset draws of a step — and the oracle follows."""
+  _need_gpu()
+  n = 512
+  env, orc = _make(cluttered_cells, n, seed=77, max_steps=1)
+  env.reset(); orc.reset()
+  first = env.agent_state.clone()
+  _cmp(env, orc, 'reset 1')
+  env.reset(); orc.reset()
+  _cmp(env, orc, 'reset 2')
+  second = env.agent_state.clone()
+  assert int((first != second).any(dim=0).sum()) > n * 0.9          # practically every env drew new spawns
+  # max_steps = 1: the very first step auto-resets every env (step index 0); those draws differ from both explicit resets
+  act = np.full((3, orc.stride), 6, np.uint8)
+  env.step(torch.from_numpy(act).to(env.device)); orc.step(act)
+  _cmp_step(env, orc, 'auto-reset at step 0')
+  third = env.agent_state.clone()
+  assert int((third != second).any(dim=0).sum()) > n * 0.9 and int((third != first).any(dim=0).sum()) > n * 0.9
+  # a masked reset half way counts as a reset call on both sides
+  mask = np.zeros(orc.stride, np.uint8); mask[::2] = 1
+  env.reset(mask=torch.from_numpy(mask).to(env.device)); orc.reset(mask=mask)
+  _cmp(env, orc, 'masked reset')
+  env.close()
+
+
 def test_default_make_is_the_unshaped_reference_env():
   """make(env_id) with no kwargs is gym.make's env: rewards are the env rewards (multigrid.py:881-883; 0 or 1 - 0.9 s/max_steps,
   never a shaped +0.02 that v8's controller would take for a goal touch, v8_robust_ppo.py:181) and the done step returns the
