@@ -126,6 +126,9 @@ def main():
                   '(mutable-grid kernel: DoorKey / Meetup / random Cluttered), not the BASELINE metric')
   ap.add_argument('--also-envs', type=int, default=131072, help='second, short measurement at this many envs per GPU '
                   "(BASELINE config 3's literal per-GPU shard at 8 GPUs), reported under 'also'; 0 = off")
+  ap.add_argument('--rollout-envs', type=int, default=131072, help='third, short measurement: the fused K-step rollout launch at this '
+                  "many envs per GPU, reported under 'rollout'; 0 = off")
+  ap.add_argument('--rollout-k', type=int, default=32)
   ap.add_argument('--stagger', action='store_true', help='start the 64-env chunks at staggered episode ages, so that every launch '
                   'auto-resets 1/max_steps of the envs (default: lock-step, all envs auto-reset in the same launch)')
   ap.add_argument('--rehearse-cpu', action='store_true', help='launcher rehearsal without a GPU: ranks rendezvous (gloo), '
@@ -254,10 +257,49 @@ def main():
     env.close()
     return res
 
+  def measure_rollout(envs_per_gpu, K, reps):
+    """The fused K-step launch (mg_rollout_random: on-device random actions, env state in registers, trajectory
+    buffers [K][...]) — a different kernel with its own byte count: no action read, env_state traffic once per K steps."""
+    base, n = shard.shard_range(rank, world, envs_per_gpu)
+    env = multigrid_amd.make_batched(args.env_id, n, device=local_rank, seed=0xC0FFEE, env_id_base=base,
+                                     shaping='v8', auto_reset=True)
+    A, V = env.n_agents, env.view_size
+    env.reset()
+    traj = env.rollout_random(K)
+    env.rollout_random(K, out=traj)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(reps):
+      env.rollout_random(K, out=traj)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    if dist is not None:
+      dist.barrier()
+    kernel_ms = ev0.elapsed_time(ev1) / (reps * K)
+    wall, value = shard.aggregate(dist, wall, float(n) * A * K * reps, world)
+    kernel_ms, _ = shard.aggregate(dist, kernel_ms, 0.0, world)
+    b_alg = A * V * V * 3 + env._dir_done.shape[1] + 8 * A + env.slots + 2.0 * 4 * (A + 1) / K
+    errs = env.check_errors()
+    env.close()
+    return {'workload': 'mg_rollout_random: %d fused steps per launch, %d envs per GPU, actions drawn on device (Philox), every '
+                        "step's obs / rewards / dir-done / actions written to [K][...] trajectory buffers" % (K, n),
+            'value': value, 'unit': 'agent-steps/s', 'env_steps_timed': K * reps, 'kernel_ms_per_step': kernel_ms,
+            'alg_bytes_per_env_step': b_alg,
+            'roofline_frac': b_alg * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'roofline_frac_at_the_step_kernels_308B': B_ALG_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'device_errors': errs}
+
   m = measure(args.envs, args.warmup, args.steps, long_cycle=True)
   also = None
   if headline and args.also_envs and args.also_envs != args.envs:
     also = measure(args.also_envs, min(args.warmup, 100), min(args.steps, 500))
+
+  roll = None
+  if headline and args.rollout_envs:
+    roll = measure_rollout(args.rollout_envs, args.rollout_k, max(1, min(args.steps, 640) // args.rollout_k))
 
   if rank == 0:
     n, A, V = m['n'], m['A'], m['V']
@@ -289,6 +331,8 @@ def main():
       out['also'] = {'workload': "same env, %d envs per GPU (BASELINE config 3's per-GPU shard of 1M envs over 8 GPUs)" % also['n'],
                      'value': also['value'], 'unit': 'agent-steps/s', 'kernel_ms': also['kernel_ms'],
                      'roofline_frac': a_ach / HBM_PEAK_GBS, 'launch': also['launch'], 'device_errors': also['errs']}
+    if roll is not None:
+      out['rollout'] = roll
     if world == 1 and not args.no_cpu_baseline and headline:
       out['cpu_baseline'] = cpu_baseline(m['cells'], args.cpu_seconds)
     sys.stdout.flush()
