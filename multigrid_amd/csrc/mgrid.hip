@@ -670,7 +670,9 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
 #pragma unroll
       for (int a = 0; a < A; ++a) {
         const int64_t i = (int64_t)a * p.stride + n;
-        if (p.reward_f32) {                                   // torch.FloatTensor(rewards) (v8:311), done at the source
+        // (not in the FAST step instantiation: the wave-uniform branch alone cost the headline kernel 1.1 us of 50.8;
+        //  a float32 handle steps through the general instantiation)
+        if ((!FAST || ROLL) && p.reward_f32) {                // torch.FloatTensor(rewards) (v8:311), done at the source
           const float r32 = (float)out_rew[a];
           if (ROLL) __builtin_nontemporal_store(r32, reinterpret_cast<float*>(p.reward) + i);
           else reinterpret_cast<float*>(p.reward)[i] = r32;
@@ -1338,7 +1340,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   }
   const bool table = launch_uses_table(h);
   launch_geometry(h, table, &nw, &grid, &lds);
-  const int fast = (op == OP_STEP && !order && !respawn && !reset_spawn && !random_actions && !h->buf.env_reward) ? 1 : 0;
+  const int fast = (op == OP_STEP && !order && !respawn && !reset_spawn && !random_actions && !h->buf.env_reward && !p.reward_f32) ? 1 : 0;
   hipLaunchKernelGGL(table ? h->var->table[fast] : h->var->generic[fast], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
   HIP_TRY(hipGetLastError());
   if (op == OP_RESET) h->reset_epoch += 1;
@@ -1787,8 +1789,11 @@ int noalloc_device(int device, NoAllocDevice* out) {
     if (rc == MG_OK) {
       (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device);
       for (const Variant& v : kVariants) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(v.generic[1]), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
-        if (e != hipSuccess) { rc = fail(MG_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); break; }
+        for (kernel_fn fn : {v.generic[0], v.generic[1]}) {
+          e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+          if (e != hipSuccess) rc = fail(MG_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        }
+        if (rc != MG_OK) break;
       }
     }
     if (rc == MG_OK) { d.ptr = static_cast<unsigned char*>(ptr); d.n_cu = n_cu < 1 ? 1 : n_cu; d.ready = true; }
@@ -1866,7 +1871,7 @@ int mg_step_noalloc(const mg_config* cfg, int device, void* hip_stream, uint64_t
   p.reward_f32 = c.reward_dtype == MG_REWARD_F32 ? 1 : 0;
   int nw; unsigned grid; size_t lds;
   launch_geometry(&hh, false, &nw, &grid, &lds);
-  hipLaunchKernelGGL(var->generic[1], dim3(grid), dim3(nw * kWave), lds, stream, p);
+  hipLaunchKernelGGL(var->generic[p.reward_f32 ? 0 : 1], dim3(grid), dim3(nw * kWave), lds, stream, p);   // FAST is float64-only
   HIP_TRY(hipGetLastError());
   if (err_out) HIP_TRY(hipMemcpyAsync(err_out, err, 4, hipMemcpyDeviceToDevice, stream));
   return MG_OK;

@@ -27,7 +27,7 @@ def _run(cells, n, steps, seed, **kw):
   cells_dev = torch.from_numpy(np.ascontiguousarray(cells)).to(dev)
   st = env._env_state.clone()
   obs = torch.full((A, S, V, V, 3), 0xCD, dtype=torch.uint8, device=dev)
-  rew = torch.full((A, S), float('nan'), dtype=torch.float64, device=dev)
+  rew = torch.full((A, S), float('nan'), dtype=env._reward.dtype, device=dev)          # float32 with reward_dtype='f32'
   dd = torch.full((S, env._dir_done.shape[1]), 0xCD, dtype=torch.uint8, device=dev)
   err = torch.full((1,), 0x7FFFFFFF, dtype=torch.int32, device=dev)
   stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -43,7 +43,8 @@ def _run(cells, n, steps, seed, **kw):
     w = 'step %d' % t
     assert torch.equal(st[:n], env._env_state[:n]), w + ' env_state'
     assert torch.equal(obs[:, :n], env._obs_image[:, :n]), w + ' obs_image'
-    assert torch.equal(rew[:, :n].view(torch.int64), env._reward[:, :n].view(torch.int64)), w + ' reward'
+    bits = torch.int64 if rew.dtype == torch.float64 else torch.int32
+    assert torch.equal(rew[:, :n].view(bits), env._reward[:, :n].view(bits)), w + ' reward'
     assert torch.equal(dd[:n, :A + 1], env._dir_done[:n, :A + 1]), w + ' dir_done'
     assert int(err.item()) == 0 and env.check_errors() == 0, w
     touches += int((env.reward >= 4.5).sum().item()) if kw.get('shaping', 'v8') == 'v8' else 0
@@ -63,6 +64,8 @@ def test_noalloc_step_matches_mg_step_twice_in_a_row(cluttered_cells, empty_cell
   _run(small, 1000, 60, seed=9, n_agents=2, view_size=7, max_steps=25)
   # and the first shape again at a ragged size (stale tables of the small grid must be gone)
   _run(cluttered_cells, 333, 40, seed=11)
+  # float32 rewards (the general instantiation on both sides)
+  _run(cluttered_cells, 200, 30, seed=12, reward_dtype='f32')
 
 
 def test_noalloc_rejects_what_the_scratch_array_cannot_hold(cluttered_cells):
