@@ -30,6 +30,9 @@ def main(argv=None):
   ap.add_argument('--no-graph', action='store_true')
   ap.add_argument('--policy', default='simple', choices=['simple', 'multigrid_net'],
                   help="simple = v8's SimplePPOAgent per agent; multigrid_net = networks/multigrid_network.py per agent (+ value head)")
+  ap.add_argument('--backend', default='nccl', help='torch.distributed backend when several ranks run (nccl = RCCL); gloo to rehearse')
+  ap.add_argument('--all-on-device0', action='store_true', help='rehearsal: every rank uses cuda:0')
+  ap.add_argument('--dump-weights', default=None, help='write this rank\'s final policy state_dict to <path>.rank<r>.pt (tests)')
   args = ap.parse_args(argv)
 
   import torch
@@ -39,10 +42,13 @@ def main(argv=None):
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  local_rank = 0 if args.all_on_device0 else int(os.environ.get('LOCAL_RANK', '0'))
   torch.cuda.set_device(local_rank)
   if world > 1:
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if args.backend == 'nccl':
+      dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+      dist.init_process_group(args.backend)
   base, n = shard.shard_range(rank, world, args.envs)
   env = multigrid_amd.make_batched(args.env_id, n, device=local_rank, seed=args.seed, env_id_base=base,
                                    shaping='v8', auto_reset=True)
@@ -67,6 +73,8 @@ def main(argv=None):
       print(json.dumps({'iter': it, 'episodes': st['episodes'], 'mean_collective_return': st['mean_collective_return'],
                         'goal_touches': st['goal_touches'], 'loss': losses, 'best_window': best if best > float('-inf') else None,
                         'agent_steps_per_s': steps / (time.time() - t0)}), flush=True)
+  if args.dump_weights:
+    torch.save({k: v.detach().cpu() for k, v in ctl.policy.state_dict().items()}, '%s.rank%d.pt' % (args.dump_weights, rank))
   env.close()
   if world > 1:
     dist.destroy_process_group()

@@ -468,3 +468,4 @@ def test_untrained_returns_agree_with_the_reference_log():
   mean, sd = float(ret.mean()), float(ret.std())
   assert -9.5 < mean < -4.5, mean          # reference's first ten episodes: -6.3 +- 3.6 / sqrt(10)
   assert 1.5 < sd < 8.0, sd                # its episode-to-episode spread there: 3.6
+
