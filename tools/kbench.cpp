@@ -114,6 +114,12 @@ int main(int argc, char** argv) {
     printf("%-40s n=%lld  median %.2f us  min %.2f us  alg %.0f GB/s (%.1f%% of 8 TB/s, %.0f B/env-step)  %.3e agent-steps/s  err=%u\n",
            argv[5 + i], (long long)n, med, mn, env_bytes * n / med / 1e3, env_bytes * n / med / 1e3 / 80.0, env_bytes,
            (double)A * n / (med * 1e-6), err);
+    if (getenv("MG_KBENCH_GEOMETRY")) {      // launch geometry of the handle (workgroup size, grid, LDS per workgroup)
+      auto info = (decltype(&mg_get_launch_info))dlsym(apis[i].dl, "mg_get_launch_info");
+      int32_t path = 0, bt = 0, gb = 0, lds = 0;
+      if (info && info(apis[i].h, &path, &bt, &gb, &lds) == MG_OK)
+        printf("    geometry: %d threads x %d workgroups, %d B LDS per workgroup (%d waves in flight)\n", bt, gb, lds, bt / 64 * gb);
+    }
   }
   return 0;
 }
