@@ -211,3 +211,103 @@ def test_lavawall_looks_like_a_wall_kills_like_lava_and_is_transparent(make, emp
   _, rew, done, _ = e.step([2, 6, 6], respawn=[(3, 3, 1), (-1, -1, 0), (-1, -1, 0)])
   assert e.agent_pos[0] == (3, 3) and e.env_rewards[0] == 0        # finished on the LavaWall, no reward, respawned
   assert e.cell(7, 5) != EMPTY          # the object itself is still there
+
+
+# ----------------------------------------------------------------------------------------------
+# Mutable-grid scenarios (BASELINE config 4), hand-derived like K1-K14.  They are not test functions themselves: each
+# takes a small front-end (C oracle, Python restatement, or the HIP library through the C ABI) and asserts on it.
+# ----------------------------------------------------------------------------------------------
+KIND_KEY_YELLOW = 5 * 8 + 4                 # MG_KIND_ID(key, yellow) (include/mgrid.h)
+DOORKEY_GEN = (3, 2, 1, 3)                  # split_idx, door_idx, key (x, y)
+#   y0  W W W W W W
+#   y1  W . . W . W
+#   y2  W . . D . W        D = locked yellow door, K = yellow key, G = goal
+#   y3  W K a W . W        a = agent 0 at (2,3) facing west (dir 2)
+#   y4  W . . W G W
+#   y5  W W W W W W
+
+
+def doorkey_known_answers(e):
+  """DoorKey 6x6, one agent, 15 steps (doorkey.py:34-86; multigrid.py:815-961, 112-122).  `e`: dict of callables
+  step(act, respawn=None, objdrop=None) -> (image of agent 0, env rewards, done), pos(), dir(), cell(x, y), carry(), obs()."""
+  KEY, DOOR_LOCKED, DOOR_OPEN, DOOR_CLOSED, EMPTY, WALL = (5, 4, 0), (4, 4, 2), (4, 4, 0), (4, 4, 1), (1, 0, 0), (2, 5, 0)
+  # generator (doorkey.py:34-67)
+  assert e['cell'](3, 2) == DOOR_LOCKED and e['cell'](1, 3) == KEY and e['cell'](4, 4) == (8, 1, 0)
+  assert all(e['cell'](3, y) == WALL for y in (0, 1, 3, 4, 5))
+  assert e['cell'](2, 3) == (10, 0, 2)
+  img = e['obs']()
+  assert tuple(img[3, 6]) == EMPTY and tuple(img[3, 5]) == KEY     # own cell, the key in front
+  # 1 pickup (multigrid.py:926-938): key leaves the grid, shows on the agent's own view cell (:1029-1033)
+  img, rew, done = e['step'](3)
+  assert e['carry']() == KIND_KEY_YELLOW and e['cell'](1, 3) == EMPTY
+  assert tuple(img[3, 6]) == KEY and tuple(img[3, 5]) == EMPTY
+  # 2 toggle on an empty cell: nothing (:953-961)
+  e['step'](5)
+  assert e['carry']() == KIND_KEY_YELLOW
+  # 3-5 right, forward, right -> (2,2) facing east, locked door ahead
+  e['step'](1); e['step'](2)
+  img, _, _ = e['step'](1)
+  assert e['pos']() == (2, 2) and e['dir']() == 0
+  assert tuple(img[3, 5]) == DOOR_LOCKED and tuple(img[3, 4]) == (0, 0, 0)   # closed door hides what is behind
+  # 6 forward into a locked door: no move (can_overlap false)
+  e['step'](2)
+  assert e['pos']() == (2, 2)
+  # 7 toggle with the matching key: unlocked and open (multigrid.py:112-119); key is kept
+  img, _, _ = e['step'](5)
+  assert e['cell'](3, 2) == DOOR_OPEN and e['carry']() == KIND_KEY_YELLOW
+  assert tuple(img[3, 5]) == DOOR_OPEN and tuple(img[3, 4]) == EMPTY
+  # 8-9 toggle again: an unlocked door flips closed, then open (:121)
+  e['step'](5)
+  assert e['cell'](3, 2) == DOOR_CLOSED
+  e['step'](5)
+  assert e['cell'](3, 2) == DOOR_OPEN
+  # 10 forward onto the open door: move_agent overwrites the door object (:834-847)
+  e['step'](2)
+  assert e['pos']() == (3, 2) and e['cell'](3, 2) == (10, 0, 0)
+  # 11 forward: the door is gone for good
+  e['step'](2)
+  assert e['pos']() == (4, 2) and e['cell'](3, 2) == EMPTY
+  # 12-13 right, forward -> (4,3) facing south, goal ahead
+  e['step'](1); e['step'](2)
+  assert e['pos']() == (4, 3) and e['dir']() == 1
+  # 14 drop in front of the goal: cell not empty, nothing happens (:940-951)
+  e['step'](4)
+  assert e['carry']() == KIND_KEY_YELLOW and e['cell'](4, 4) == (8, 1, 0)
+  # 15 forward into the goal: agent_is_done re-places the key anywhere, then the agent on the left (:815-832)
+  img, rew, done = e['step'](2, respawn=(1, 1, 0), objdrop=(4, 1))
+  assert rew == [1 - 0.9 * (15 / 360)] and done
+  assert e['carry']() == 0 and e['cell'](4, 1) == KEY and e['pos']() == (1, 1) and e['cell'](4, 4) == (8, 1, 0)
+
+
+def meetup_known_answers(m):
+  """Meetup 6x6, 2 agents, goal doors at (1,1) and (4,4), one wall at (3,3) (meetup.py:26-95; multigrid.py:1043-1065):
+  distances, argmin tie-breaking, the +1 / done rule, a locked door stays locked.  `m`: reset(spawn, scatter) -> images,
+  step(actions, order) -> (env rewards, done), aux() -> 4 words, agent_pos(), cell(x, y)."""
+  imgs = m.reset([(2, 1, 0), (3, 4, 2)], [(1, 1), (4, 4), (3, 3)])
+  img = imgs[0]
+  assert img.shape == (6, 6, 3) and np.array_equal(imgs[0], imgs[1])
+  assert tuple(img[1, 1]) == (4, 0, 2) and tuple(img[4, 4]) == (4, 0, 2) and tuple(img[3, 3]) == (2, 5, 0)
+  assert tuple(img[2, 1]) == (10, 0, 0) and tuple(img[3, 4]) == (10, 1, 2) and tuple(img[2, 2]) == (1, 0, 0)
+  # goal 0: |1-2|+0 + |1-3|+|1-4| = 1 + 5 = 6; goal 1: 2+3 + 1+0 = 6 -> tie, argmin takes goal 0
+  aux = m.aux()
+  assert aux[0] == (1 | 1 << 6) | (4 | 4 << 6) << 16 and aux[1] == 0xFFFFFFFF and aux[2] == 0xFFFFFFFF
+  assert aux[3] == 1 | 5 << 8
+  # agent 1 steps west to (2,4): goal 0 sum = 1 + (1+3) = 5, goal 1 sum = 5 + 2 = 7 -> goal 0; reward = 5 - 4
+  rew, done = m.step([6, 2], [0, 1])
+  assert rew == [0.0, 1.0] and not done
+  # agent 0 turns left (faces north), agent 1 turns right (faces north): no change in distance
+  rew, _ = m.step([0, 1], [1, 0])
+  assert rew == [0.0, 0.0]
+  # agent 1 walks north three times: (2,3), (2,2); (2,1) is agent 0's cell -> blocked
+  for want in ([0.0, 1.0], [0.0, 1.0], [0.0, 0.0]):
+    rew, _ = m.step([6, 2], [0, 1])
+    assert rew == want
+  assert m.agent_pos() == [(2, 1), (2, 2)]
+  # agent 1 west to (1,2): distances 1 and 1 -> sum == n_agents: +1 each and done
+  m.step([6, 0], [0, 1])     # face west
+  rew, done = m.step([6, 2], [0, 1])
+  assert rew == [1.0, 2.0] and done
+  # picking up / toggling the locked red door without a key changes nothing (multigrid.py:112-119)
+  m.step([6, 3], [0, 1])
+  m.step([6, 5], [0, 1])
+  assert m.cell(1, 1) == (4, 0, 2)

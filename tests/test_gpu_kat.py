@@ -19,3 +19,18 @@ def make():
     pytest.skip('no GPU')
   from device_adapter import DevReplay
   return DevReplay
+
+
+def test_doorkey_known_answers_on_device(make):
+  """BASELINE config 4 without an oracle: the hand-derived 15-step DoorKey scenario (generator, pickup, locked door, unlock,
+  close / open, the open door destroyed by walking through it, drop refused, goal touch with the key re-placed) through the
+  mutable-grid kernel.  doorkey.py:34-86; multigrid.py:815-961, 112-122."""
+  from device_adapter import doorkey_front_end
+  doorkey_known_answers(doorkey_front_end(DOORKEY_GEN, [(2, 3, 2)]))
+
+
+def test_meetup_known_answers_on_device(make):
+  """Fully observed Meetup scenario (whole-grid obs with the agents in their cells, distance reward, argmin tie-break, the
+  +1 / done rule) through the mutable-grid kernel.  meetup.py:26-95; multigrid.py:1043-1065."""
+  from device_adapter import DevMeetup
+  meetup_known_answers(DevMeetup())

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from oracle import c_oracle, py_ref_env
+from kat_cases import DOORKEY_GEN as GEN, doorkey_known_answers
 
 
 class Feed:
@@ -63,7 +64,6 @@ def py_carry(env):
 # ----------------------------------------------------------------------------------------------
 # known answers, derived by hand from the reference source
 # ----------------------------------------------------------------------------------------------
-GEN = (3, 2, 1, 3)            # split_idx, door_idx, key (x, y)
 #   y0  W W W W W W
 #   y1  W . . W . W
 #   y2  W . . D . W        D = locked yellow door, K = yellow key, G = goal
@@ -114,54 +114,7 @@ def _kat_py():
 
 @pytest.mark.parametrize('which', ['c', 'py'])
 def test_doorkey_known_answers(which):
-  e = _kat_c() if which == 'c' else _kat_py()
-  KEY, DOOR_LOCKED, DOOR_OPEN, DOOR_CLOSED, EMPTY, WALL = (5, 4, 0), (4, 4, 2), (4, 4, 0), (4, 4, 1), (1, 0, 0), (2, 5, 0)
-  # generator (doorkey.py:34-67)
-  assert e['cell'](3, 2) == DOOR_LOCKED and e['cell'](1, 3) == KEY and e['cell'](4, 4) == (8, 1, 0)
-  assert all(e['cell'](3, y) == WALL for y in (0, 1, 3, 4, 5))
-  assert e['cell'](2, 3) == (10, 0, 2)
-  img = e['obs']()
-  assert tuple(img[3, 6]) == EMPTY and tuple(img[3, 5]) == KEY     # own cell, the key in front
-  # 1 pickup (multigrid.py:926-938): key leaves the grid, shows on the agent's own view cell (:1029-1033)
-  img, rew, done = e['step'](3)
-  assert e['carry']() == c_oracle.kind_id(5, 4) and e['cell'](1, 3) == EMPTY
-  assert tuple(img[3, 6]) == KEY and tuple(img[3, 5]) == EMPTY
-  # 2 toggle on an empty cell: nothing (:953-961)
-  e['step'](5)
-  assert e['carry']() == c_oracle.kind_id(5, 4)
-  # 3-5 right, forward, right -> (2,2) facing east, locked door ahead
-  e['step'](1); e['step'](2)
-  img, _, _ = e['step'](1)
-  assert e['pos']() == (2, 2) and e['dir']() == 0
-  assert tuple(img[3, 5]) == DOOR_LOCKED and tuple(img[3, 4]) == (0, 0, 0)   # closed door hides what is behind
-  # 6 forward into a locked door: no move (can_overlap false)
-  e['step'](2)
-  assert e['pos']() == (2, 2)
-  # 7 toggle with the matching key: unlocked and open (multigrid.py:112-119); key is kept
-  img, _, _ = e['step'](5)
-  assert e['cell'](3, 2) == DOOR_OPEN and e['carry']() == c_oracle.kind_id(5, 4)
-  assert tuple(img[3, 5]) == DOOR_OPEN and tuple(img[3, 4]) == EMPTY
-  # 8-9 toggle again: an unlocked door flips closed, then open (:121)
-  e['step'](5)
-  assert e['cell'](3, 2) == DOOR_CLOSED
-  e['step'](5)
-  assert e['cell'](3, 2) == DOOR_OPEN
-  # 10 forward onto the open door: move_agent overwrites the door object (:834-847)
-  e['step'](2)
-  assert e['pos']() == (3, 2) and e['cell'](3, 2) == (10, 0, 0)
-  # 11 forward: the door is gone for good
-  e['step'](2)
-  assert e['pos']() == (4, 2) and e['cell'](3, 2) == EMPTY
-  # 12-13 right, forward -> (4,3) facing south, goal ahead
-  e['step'](1); e['step'](2)
-  assert e['pos']() == (4, 3) and e['dir']() == 1
-  # 14 drop in front of the goal: cell not empty, nothing happens (:940-951)
-  e['step'](4)
-  assert e['carry']() == c_oracle.kind_id(5, 4) and e['cell'](4, 4) == (8, 1, 0)
-  # 15 forward into the goal: agent_is_done re-places the key anywhere, then the agent on the left (:815-832)
-  img, rew, done = e['step'](2, respawn=(1, 1, 0), objdrop=(4, 1))
-  assert rew == [1 - 0.9 * (15 / 360)] and done
-  assert e['carry']() == 0 and e['cell'](4, 1) == KEY and e['pos']() == (1, 1) and e['cell'](4, 4) == (8, 1, 0)
+  doorkey_known_answers(_kat_c() if which == 'c' else _kat_py())
 
 
 def test_doorkey_generator_ranges():

@@ -8,6 +8,7 @@ import pytest
 
 from oracle import c_oracle, py_ref_env
 from test_oracle_doorkey import Feed, py_grid, step_queue
+from kat_cases import meetup_known_answers
 
 
 def layout_queue(scatter, spawn):
@@ -19,38 +20,33 @@ def layout_queue(scatter, spawn):
   return q
 
 
+class _CMeetup:
+  """The C oracle behind the small interface kat_cases.meetup_known_answers drives"""
+
+  def __init__(self):
+    self.env = c_oracle.OracleEnv(None, W=6, H=6, A=2, V=7, max_steps=50, kind='meetup', n_goals=2, n_clutter=1)
+
+  def reset(self, spawn, scatter):
+    obs = self.env.reset(spawn=spawn, scatter=scatter)
+    assert self.env.errors() == 0
+    return obs['image']
+
+  def step(self, actions, order):
+    _, _, done, _ = self.env.step(actions, order=order, respawn=[(-1, -1, 0)] * 2)
+    return [float(r) for r in self.env.env_rewards], done
+
+  def aux(self):
+    return [int(w) for w in self.env.aux_words()]
+
+  def agent_pos(self):
+    return [tuple(int(v) for v in p) for p in self.env.agent_pos]
+
+  def cell(self, x, y):
+    return tuple(int(v) for v in self.env.grid()[y, x])
+
+
 def test_meetup_known_answers():
-  """6x6, 2 agents, goals at (1,1) and (4,4): distances, argmin tie-breaking, the +1 / done rule."""
-  env = c_oracle.OracleEnv(None, W=6, H=6, A=2, V=7, max_steps=50, kind='meetup', n_goals=2, n_clutter=1)
-  obs = env.reset(spawn=[(2, 1, 0), (3, 4, 2)], scatter=[(1, 1), (4, 4), (3, 3)])
-  assert env.errors() == 0
-  img = obs['image'][0]
-  assert img.shape == (6, 6, 3) and np.array_equal(obs['image'][0], obs['image'][1])
-  assert tuple(img[1, 1]) == (4, 0, 2) and tuple(img[4, 4]) == (4, 0, 2) and tuple(img[3, 3]) == (2, 5, 0)
-  assert tuple(img[2, 1]) == (10, 0, 0) and tuple(img[3, 4]) == (10, 1, 2) and tuple(img[2, 2]) == (1, 0, 0)
-  # goal 0: |1-2|+0 + |1-3|+|1-4| = 1 + 5 = 6; goal 1: 2+3 + 1+0 = 6 -> tie, argmin takes goal 0
-  aux = env.aux_words()
-  assert aux[0] == (1 | 1 << 6) | (4 | 4 << 6) << 16 and aux[1] == 0xFFFFFFFF and aux[2] == 0xFFFFFFFF
-  assert aux[3] == 1 | 5 << 8
-  # agent 1 steps west to (2,4): goal 0 sum = 1 + (1+3) = 5, goal 1 sum = 5 + 2 = 7 -> goal 0; reward = 5 - 4
-  _, rew, done, _ = env.step([6, 2], order=[0, 1], respawn=[(-1, -1, 0)] * 2)
-  assert list(env.env_rewards) == [0.0, 1.0] and not done
-  # agent 0 turns left (faces north), agent 1 turns right (faces north): no change in distance
-  env.step([0, 1], order=[1, 0], respawn=[(-1, -1, 0)] * 2)
-  assert list(env.env_rewards) == [0.0, 0.0]
-  # agent 1 walks north three times: (2,3), (2,2); (2,1) is agent 0's cell -> blocked
-  for want in ([0.0, 1.0], [0.0, 1.0], [0.0, 0.0]):
-    env.step([6, 2], order=[0, 1], respawn=[(-1, -1, 0)] * 2)
-    assert list(env.env_rewards) == want
-  assert [tuple(p) for p in env.agent_pos] == [(2, 1), (2, 2)]
-  # agent 1 west to (1,2): distances 1 and 1 -> sum == n_agents: +1 each and done
-  env.step([6, 0], order=[0, 1], respawn=[(-1, -1, 0)] * 2)     # face west
-  _, rew, done, _ = env.step([6, 2], order=[0, 1], respawn=[(-1, -1, 0)] * 2)
-  assert list(env.env_rewards) == [1.0, 2.0] and done
-  # toggling the locked red door without a key changes nothing (multigrid.py:112-119)
-  env.step([6, 3], order=[0, 1], respawn=[(-1, -1, 0)] * 2)
-  env.step([6, 5], order=[0, 1], respawn=[(-1, -1, 0)] * 2)
-  assert tuple(env.grid()[1, 1]) == (4, 0, 2)
+  meetup_known_answers(_CMeetup())
 
 
 def _cross(kind, size, A, steps, seed, max_steps, **gen):
