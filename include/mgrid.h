@@ -220,6 +220,15 @@ int mg_destroy(mg_handle* h);
  * invalidates the envs' state: mg_reset must be called again before the next step (MG_ESTATE otherwise). */
 int mg_set_static_map(mg_handle* h, const uint8_t* cells);
 
+/* Per-env layouts (SURVEY §8(b)'s mg_set_maps): env n resets to its OWN layout instead of one shared by all — the batched form of
+ * constructing N reference envs with N different fixed maps.  cells = DEVICE pointer uint8[n_envs][H*W*3], each env's layout as in
+ * mg_set_static_map.  The handle switches to the mutable-grid kernel (every env owns its grid; objects allowed), each env's v8
+ * shaper goal is its own first goal cell (mg_buffers.aux word 0, bits 0..15), agents spawn anywhere.  Unknown cell types are
+ * imported as walls and reported as MG_ERR_BAD_MAP (mg_check_errors), as are layouts with fewer free cells than agents.
+ * MG_KIND_STATIC handles only; mg_reset is required afterwards; a later mg_set_static_map goes back to one shared layout.
+ * mg_get_buffers must be called again afterwards (carry / grid / aux appear). */
+int mg_set_maps(mg_handle* h, const uint8_t* cells);
+
 /* Fixed start cells on a static map (shared-map kernels only).  xy = host int8[A][2].
  *   MG_FIXED_ALWAYS   EmptyEnv(agent_start='fixed').place_one_agent (multigrid_envs/empty.py:33-36, 72-104): every
  *                     placement — reset and the respawn after a goal / lava touch — puts the agent on its start cell

@@ -76,6 +76,18 @@ class BatchedMultiGrid:
     if use_torch_stream:
       s = torch.cuda.current_stream(self.device)
       _lib.check(self.L.mg_set_stream(self.h, C.c_void_p(s.cuda_stream)))
+    self._bind()
+    # action buffer in the layout the kernel reads: one dword per env (two with five agents), byte a = agent a's
+    # action.  Policies write `env.actions[:N, a]`; `step()` with no argument consumes it.
+    A, S, dev = self.n_agents, self.stride, self.device
+    self.slots = _lib.slots(A)
+    self.actions = torch.full((S, self.slots), 6, dtype=torch.uint8, device=dev)
+    gx, gy = C.c_int32(), C.c_int32()
+    _lib.check(self.L.mg_get_goal(self.h, C.byref(gx), C.byref(gy)))
+    self.goal_pos = (gx.value, gy.value)
+
+  def _bind(self):
+    """Alias the library's device buffers as tensors (again after a call that creates buffers: set_maps)."""
     b = _lib.MgBuffers()
     _lib.check(self.L.mg_get_buffers(self.h, C.byref(b)))
     self.stride = S = int(b.env_stride)
@@ -104,13 +116,16 @@ class BatchedMultiGrid:
       self.grid_words = int(b.grid_words)
       self.carry = _alias(b.carry, (S,) if A <= 4 else (S, 2), '<i4', dev)[:n]   # byte a = kind agent a carries
       self.grid_blocked = _alias(b.grid, (S // 64, self.grid_words * 4, 64), '|u1', dev)  # [chunk][cell][lane], include/mgrid.h
-    # action buffer in the layout the kernel reads: one dword per env (two with five agents), byte a = agent a's
-    # action.  Policies write `env.actions[:N, a]`; `step()` with no argument consumes it.
-    self.slots = _lib.slots(A)
-    self.actions = torch.full((S, self.slots), 6, dtype=torch.uint8, device=dev)
-    gx, gy = C.c_int32(), C.c_int32()
-    _lib.check(self.L.mg_get_goal(self.h, C.byref(gx), C.byref(gy)))
-    self.goal_pos = (gx.value, gy.value)
+
+  def set_maps(self, cells):
+    """Per-env layouts (mg_set_maps): cells uint8[N, H, W, 3], env n resets to cells[n] from now on; objects allowed.
+    The handle runs the mutable-grid kernel afterwards; call reset() next."""
+    t = torch.as_tensor(cells, device=self.device).to(torch.uint8).contiguous()
+    assert tuple(t.shape) == (self.n_envs, self.height, self.width, 3), tuple(t.shape)
+    _lib.check(self.L.mg_set_maps(self.h, C.c_void_p(t.data_ptr())))
+    torch.cuda.current_stream(self.device).synchronize()      # `t` may go away once the import kernel has read it
+    self.cells = None
+    self._bind()
 
   # ---- lifetime -----------------------------------------------------------------------------
   def close(self):

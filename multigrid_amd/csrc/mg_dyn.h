@@ -514,7 +514,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       out_rew[a] = rew[a];
       if (p.shaping != MG_SHAPING_NONE) {
         // get_goal_position (v8:159-169): the per-env scattered goal of a Cluttered layout, else the handle's
-        const bool own = (p.kind == MG_KIND_CLUTTERED && p.n_goals != 0) || p.kind == MG_KIND_FOURROOMS;
+        const bool own = (p.kind == MG_KIND_CLUTTERED && p.n_goals != 0) || p.kind == MG_KIND_FOURROOMS || p.grid0 != nullptr;
         const int gx = own ? (int)(goal[0] & 63u) : p.gx, gy = own ? (int)((goal[0] >> 6) & 63u) : p.gy;
         shw[a] = v8_shape<true>(p, dist, shw[a], pd_get(pd, a), (actw >> (3 * a)) & 7u, rew[a], out_rew[a], gx, gy);
       }
@@ -533,7 +533,12 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   // ---- reset() (multigrid.py:466-501) / auto-reset: _gen_grid on this env's own grid ------------
   const bool do_reset = (!is_step) ? (p.mask ? (p.mask[active ? n : 0] != 0) : true) : (done_flag && p.auto_reset);
   if (do_reset) {
-    for (int ci = 0; ci < cells; ++ci) gs((int)pidx[ci] * kCellB, (base[ci >> 2] >> (8 * (ci & 3))) & 255u);
+    if (p.grid0) {                         // mg_set_maps: this env's own layout (a lane's byte of every cell row)
+      const uint8_t* t0 = reinterpret_cast<const uint8_t*>(p.grid0 + (env0 >> 6) * (int64_t)p.GW * kWave) + lane;
+      for (int ci = 0; ci < cells; ++ci) gs((int)pidx[ci] * kCellB, t0[ci * kWave]);
+    } else {
+      for (int ci = 0; ci < cells; ++ci) gs((int)pidx[ci] * kCellB, (base[ci >> 2] >> (8 * (ci & 3))) & 255u);
+    }
     carry = 0;                                                                  // multigrid.py:490
     int door = 1;
     const bool inj_gen = p.reset_gen != nullptr;

@@ -91,6 +91,7 @@ struct Params {
   // mutable-grid kernel only (mg_dyn.h)
   int32_t kind, GW;            // MG_KIND_*, grid dwords per env
   const uint32_t* base_grid;   // [GW] kind ids of the layout every reset starts from
+  const uint32_t* grid0;       // mg_set_maps: [n_chunks][GW][64] per-env layouts every reset starts from (else null)
   const uint32_t* objdrop;     // int8x4 per (env, agent)
   const uint32_t* reset_gen;   // int8x4 per env
   uint32_t* carry;             // [stride]
@@ -1024,6 +1025,40 @@ __global__ void sqrt_probe(int n, double* out) {
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= n; k += gridDim.x * blockDim.x) out[k] = __dsqrt_rn((double)k);
 }
 
+// mg_set_maps: the caller's per-env layouts (device uint8[n_envs][H*W*3] cell triples) -> kind ids in the blocked layout of
+// the per-env grids, plus every env's own shaper goal (get_goal_position, v8_robust_ppo.py:159-169: first goal scanning
+// x-major, (13,13) if none) into aux word 0.  One thread per env: a one-off import, not a hot path.
+__global__ void import_maps_kernel(const uint8_t* cells, int W, int H, int GW, int A, int64_t n_envs, uint8_t* grid0, uint32_t* aux,
+                                   uint32_t* err) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_envs) return;
+  const int ncell = W * H;
+  const uint8_t* c = cells + n * ncell * 3;
+  uint8_t* g = grid0 + (n >> 6) * (int64_t)GW * 4 * kWave + (n & 63);
+  int n_free = 0;
+  bool bad = false;
+  for (int ci = 0; ci < ncell; ++ci) {
+    const uint32_t t = c[ci * 3], col = c[ci * 3 + 1] & 7u, st = c[ci * 3 + 2];
+    uint32_t k = 0;
+    switch (t) {
+      case MG_T_UNSEEN: case MG_T_EMPTY: ++n_free; break;
+      case MG_T_WALL: case MG_T_GOAL: case MG_T_LAVA: case MG_T_FLOOR: case MG_T_KEY: case MG_T_BALL: case MG_T_BOX: k = t * 8 + col; break;
+      case MG_T_DOOR: if (st > 2) { bad = true; k = K_WALL; } else k = 128 + col * 4 + st; break;
+      default: bad = true; k = K_WALL; break;
+    }
+    g[(int64_t)ci * kWave] = (uint8_t)k;
+  }
+  uint32_t goal = 13u | (13u << 6);
+  bool found = false;
+  for (int i = 0; i < W && !found; ++i)
+    for (int j = 0; j < H; ++j)
+      if (c[(j * W + i) * 3] == MG_T_GOAL) { goal = (uint32_t)i | ((uint32_t)j << 6); found = true; break; }
+  aux[n * 4] = goal | 0xFFFF0000u;
+  aux[n * 4 + 1] = aux[n * 4 + 2] = 0xFFFFFFFFu;
+  aux[n * 4 + 3] = 0u;
+  if (bad || n_free < A) atomicOr(err, MG_ERR_BAD_MAP);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -1142,6 +1177,8 @@ struct mg_handle {
   const DynVariant* dvar;
   int GW;
   uint32_t* base_grid;
+  uint32_t* grid0;       // per-env reset templates (mg_set_maps), same blocked layout as grid
+  bool per_env_maps;
   uint32_t* carry;
   uint32_t* grid;
   uint32_t* aux;
@@ -1299,6 +1336,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   p.obs_image = h->buf.obs_image; p.reward = h->buf.reward;
   p.env_reward = h->buf.env_reward; p.dir_done = h->buf.dir_done; p.env_state = h->buf.env_state; p.err = h->err;
   p.kind = c.env_kind; p.GW = h->GW; p.base_grid = h->base_grid;
+  p.grid0 = h->per_env_maps ? h->grid0 : nullptr;
   p.objdrop = reinterpret_cast<const uint32_t*>(objdrop);
   p.reset_gen = reinterpret_cast<const uint32_t*>(reset_gen);
   p.carry = h->carry; p.grid = h->grid;
@@ -1457,7 +1495,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   mg_handle* h = new mg_handle();
   h->cfg = c; h->device = device; h->var = var; h->t = 0; h->reset_epoch = 0; h->have_map = h->have_reset = false;
   h->dynamic = false; h->dvar = dvar; h->GW = (c.width * c.height + 3) / 4;
-  h->base_grid = nullptr; h->carry = nullptr; h->grid = nullptr; h->aux = nullptr; h->obs_full = nullptr;
+  h->base_grid = nullptr; h->grid0 = nullptr; h->per_env_maps = false; h->carry = nullptr; h->grid = nullptr; h->aux = nullptr; h->obs_full = nullptr;
   h->full_obs = c.env_kind == MG_KIND_MEETUP; h->LW = c.width; h->LH = c.height;
   h->dyn_waves_cu = 8; h->fixed_mode = 0; h->fixed_pd = 0; h->fixed_pd_hi = 0;
   if (dvar) {
@@ -1558,6 +1596,7 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
     h->free_cells.assign((size_t)W * H, 0);
     for (int i = 0; i < W * H; ++i) h->free_cells[i] = cells[(size_t)i * 3] <= MG_T_EMPTY;
     h->fixed_mode = 0;                      // start cells belong to the old layout
+    h->per_env_maps = false;                // and so do per-env layouts (mg_set_maps)
     int n_free = 0, gx = -1, gy = -1;
     for (int i = 0; i < W * H; ++i) {
       const uint8_t* c = cells + (size_t)i * 3;
@@ -1655,6 +1694,30 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
   h->use_table = use_table;
   h->have_map = true;
   h->have_reset = false;          // positions and grids of the old layout mean nothing on the new one
+  return MG_OK;
+}
+
+int mg_set_maps(mg_handle* h, const uint8_t* cells) {
+  if (!h || !cells) return fail(MG_EINVAL, "null argument");
+  const mg_config& c = h->cfg;
+  if (c.env_kind != MG_KIND_STATIC) return fail(MG_EINVAL, "this env_kind generates its own grids; no caller-supplied maps");
+  // every env gets its own (mutable) grid; the reset template is per env, the shared template is the bare border
+  std::vector<uint8_t> kinds((size_t)c.width * c.height, 0);
+  int rc = enable_dynamic(h, kinds, 13, 13);      // distance table large enough for the (13,13) fallback goal
+  if (rc != MG_OK) return rc;
+  DeviceGuard g(h->device);
+  if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
+  if (!h->grid0) rc = dalloc(h, &h->grid0, (size_t)h->n_chunks * h->GW * kWave);
+  if (rc == MG_OK && !h->aux) rc = dalloc(h, &h->aux, (size_t)h->stride * 4);
+  if (rc != MG_OK) return rc;
+  h->buf.aux = h->aux;
+  const unsigned blocks = (unsigned)((c.n_envs + 255) / 256);
+  hipLaunchKernelGGL(import_maps_kernel, dim3(blocks), dim3(256), 0, h->stream, cells, c.width, c.height, h->GW, c.n_agents, c.n_envs,
+                     reinterpret_cast<uint8_t*>(h->grid0), h->aux, h->err);
+  HIP_TRY(hipGetLastError());
+  h->free_cells.assign((size_t)c.width * c.height, 0);     // no fixed start cells on per-env layouts
+  h->fixed_mode = 0;
+  h->per_env_maps = true;
   return MG_OK;
 }
 

@@ -62,6 +62,7 @@ SYMBOLS = {
     'mg_create': (C.c_int, [C.POINTER(MgConfig), C.c_int, C.POINTER(C.c_void_p)]),
     'mg_destroy': (C.c_int, [C.c_void_p]),
     'mg_set_static_map': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mg_set_maps': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_set_fixed_spawn': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     'mg_reset': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_reset_inject': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

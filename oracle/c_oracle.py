@@ -339,6 +339,12 @@ class OracleBatch:
         self.L.mgo_destroy(self.envs[i])
         self.envs[i] = None
 
+  def set_maps(self, cells):
+    """Per-env layouts: cells uint8[n, H, W, 3] (the batched form of n envs built on n different fixed maps)."""
+    cells = np.ascontiguousarray(cells, dtype=np.uint8).reshape(self.n, self.W * self.H * 3)
+    for i in range(self.n):
+      self.L.mgo_set_map(self.envs[i], _p(cells[i], u8p))
+
   def reset(self, mask=None, spawn=None, gen=None, scatter=None):
     """spawn int8[A,stride,4]; gen int8[stride,4] = (split, door, key_x, key_y) (DoorKey replay);
     scatter int8[stride,n_obj,2] = accepted positions of the scattered objects (scatter kinds)."""

@@ -333,3 +333,98 @@ def test_full_size_invariants_of_generated_kinds(env_id, n):
       assert bool((inner_walls == 25).all())
   assert env.check_errors() == 0
   env.close()
+
+
+def _random_layouts(rng, n, W, H, with_objects=True):
+  """n different bordered layouts: random interior walls, one goal somewhere (a few layouts have none: the shaper's
+  (13,13) fallback), optionally keys / balls / boxes / doors / floor / lava."""
+  cells = np.zeros((n, H, W, 3), np.uint8)
+  cells[..., 0] = 1
+  cells[:, 0, :] = cells[:, H - 1, :] = cells[:, :, 0] = cells[:, :, W - 1] = (2, 5, 0)
+  for e in range(n):
+    inner = [(x, y) for y in range(1, H - 1) for x in range(1, W - 1)]
+    rng.shuffle(inner)
+    k = 0
+    for _ in range(int(rng.integers(0, (W - 2) * (H - 2) // 4))):
+      x, y = inner[k]; k += 1
+      cells[e, y, x] = (2, 5, 0)
+    if e % 9 != 8:
+      x, y = inner[k]; k += 1
+      cells[e, y, x] = (8, 1, 0)
+    if with_objects:
+      for obj in ((5, 4, 0), (6, 2, 0), (7, 3, 0), (4, 4, 2), (4, 1, 1), (4, 0, 0), (3, 2, 0), (9, 0, 0), (5, 0, 0)):
+        if rng.random() < 0.6:
+          x, y = inner[k]; k += 1
+          cells[e, y, x] = obj
+  return cells
+
+
+@pytest.mark.parametrize('W,H,A,V,objects', [(9, 9, 3, 5, True), (8, 7, 2, 7, True), (15, 15, 3, 5, False)])
+def test_per_env_maps_parity(W, H, A, V, objects):
+  """mg_set_maps: every env resets to its OWN layout (the batched form of N reference envs built on N different fixed maps)
+  — free-running against the oracle holding the same N layouts, across auto-resets, with every env's own shaper goal."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  from multigrid_amd import layouts
+  n, max_steps = 700, 35
+  rng = np.random.default_rng(W * 100 + H)
+  cells = _random_layouts(rng, n, W, H, objects)
+  env = BatchedMultiGrid(layouts.empty_bordered(W, H, goal=(W - 2, H - 2)), n_envs=n, n_agents=A, view_size=V, max_steps=max_steps,
+                         seed=7, emit_env_reward=True)
+  assert not env.mutable_grid
+  env.set_maps(cells)
+  assert env.mutable_grid and env.aux is not None
+  orc = c_oracle.OracleBatch(cells[0], n, W=W, H=H, A=A, V=V, max_steps=max_steps, shaping=1, auto_reset=1, seed=7)
+  orc.set_maps(cells)
+  env.reset()
+  orc.reset()
+  assert env.check_errors() == 0
+  # every env's goal, as imported: first goal scanning x-major, else (13,13)
+  want_goal = []
+  for e in range(n):
+    g = [(x, y) for x in range(W) for y in range(H) if cells[e, y, x, 0] == 8]
+    want_goal.append(g[0] if g else (13, 13))
+  aux0 = env.aux[:, 0].cpu().numpy().view(np.uint32) & 0xFFFF
+  assert [(int(v) & 63, int(v) >> 6) for v in aux0] == want_goal
+  touches = 0
+  for t in range(120):
+    env.step_random()
+    orc.step()
+    w = 'step %d' % t
+    assert np.array_equal(env.obs_image.cpu().numpy().reshape(A, n, -1), orc.obs_image[:, :n]), w
+    assert np.array_equal(env.reward.cpu().numpy().view(np.int64), orc.reward[:, :n].view(np.int64)), w
+    assert np.array_equal(env.done.cpu().numpy(), orc.done[:n]), w
+    touches += int((orc.env_reward[:, :n] > 0).sum())
+  carry, kinds = orc.dyn_state()
+  assert np.array_equal(env.grid_kinds().cpu().numpy(), kinds[:n])
+  assert np.array_equal(env.agent_state.cpu().numpy().view(np.uint32), orc.agent_state()[:, :n])
+  assert env.check_errors() == 0 and orc.errors() == 0 and touches > 0
+  # back to one shared layout: the handle returns to the shared-map kernel
+  import ctypes as C
+  from multigrid_amd import lib as _lib
+  shared = layouts.empty_bordered(W, H, goal=(W - 2, H - 2))
+  _lib.check(env.L.mg_set_static_map(env.h, np.ascontiguousarray(shared).ctypes.data_as(C.c_void_p)))
+  env._bind()
+  assert not env.mutable_grid
+  env.close()
+
+
+def test_per_env_maps_flag_bad_layouts():
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  from multigrid_amd import layouts, lib as _lib
+  base = layouts.empty_bordered(6, 6, goal=(4, 4))
+  cells = np.repeat(base[None], 64, axis=0).copy()
+  cells[5, 2, 2] = (11, 0, 0)                      # unknown object type
+  env = BatchedMultiGrid(base, n_envs=64, n_agents=2, view_size=5)
+  env.set_maps(cells)
+  assert env.check_errors() & _lib.ERR_BAD_MAP
+  cells[5, 2, 2] = (1, 0, 0)
+  cells[9, 1:5, 1:5] = (2, 5, 0)                   # no free cell left for the agents
+  env.set_maps(cells)
+  assert env.check_errors() & _lib.ERR_BAD_MAP
+  env.close()
+  env = BatchedMultiGrid(None, n_envs=64, kind='doorkey', size=6, n_agents=2, view_size=7)
+  with pytest.raises(_lib.MgError, match='generates its own grids'):
+    env.set_maps(np.zeros((64, 6, 6, 3), np.uint8))
+  env.close()
