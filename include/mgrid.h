@@ -229,6 +229,25 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells);
  * mg_get_buffers must be called again afterwards (carry / grid / aux appear). */
 int mg_set_maps(mg_handle* h, const uint8_t* cells);
 
+/* Episode statistics kept by the library: what run_episode keeps beside the trajectories (v8_robust_ppo.py:234-235, 246-248,
+ * 266, 273 — episode_rewards[a] += shaped_rewards[a]; goal_touches += 1 for every shaped reward >= 4.5) and what train() logs
+ * per finished episode (v8_robust_ppo.py:425), per env, on the device.  Off by default; once enabled every mg_reset* / mg_step* /
+ * mg_rollout_random call is followed, on the handle's stream, by one small kernel that folds that call's rewards and done flags
+ * in (about 30 A + 40 bytes of HBM traffic per env-step, one thread per env; a rollout's K steps are folded in one pass over
+ * its trajectory).  Sums are added per env in step order in float64: bit-identical to the reference's Python floats.
+ * touch_threshold: a reward >= it counts as a goal touch (4.5 for the v8 shaper; any positive value below 0.1 counts unshaped
+ * goal rewards, multigrid.py:879-886).  All pointers are DEVICE memory owned by the handle, agent-major like mg_buffers.reward. */
+typedef struct mg_episode_stats {
+  double*   ep_return;         /* [A][env_stride] return of the episode in progress */
+  uint32_t* ep_goal_touches;   /* [env_stride]    its goal touches so far */
+  uint32_t* ep_len;            /* [env_stride]    its steps so far */
+  double*   last_return;       /* [A][env_stride] the most recently finished episode of this env: return, */
+  uint32_t* last_goal_touches; /* [env_stride]    goal touches, */
+  uint32_t* last_len;          /* [env_stride]    length; valid once ep_count > 0 */
+  uint32_t* ep_count;          /* [env_stride]    episodes finished (done reported) since mg_enable_episode_stats */
+} mg_episode_stats;
+int mg_enable_episode_stats(mg_handle* h, double touch_threshold, mg_episode_stats* out);
+
 /* Fixed start cells on a static map (shared-map kernels only).  xy = host int8[A][2].
  *   MG_FIXED_ALWAYS   EmptyEnv(agent_start='fixed').place_one_agent (multigrid_envs/empty.py:33-36, 72-104): every
  *                     placement — reset and the respawn after a goal / lava touch — puts the agent on its start cell

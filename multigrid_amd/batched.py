@@ -127,6 +127,18 @@ class BatchedMultiGrid:
     self.cells = None
     self._bind()
 
+  def enable_episode_stats(self, touch_threshold=4.5):
+    """Per-env episode statistics kept by the library (mg_enable_episode_stats; v8_robust_ppo.py:234-273): from now on every
+    reset / step / rollout also updates `ep_return` float64[A, N], `ep_goal_touches`, `ep_len` (episode in progress) and
+    `last_return`, `last_goal_touches`, `last_len`, `ep_count` int32[N] (last finished episode).  Returns them as a dict."""
+    st = _lib.MgEpisodeStats()
+    _lib.check(self.L.mg_enable_episode_stats(self.h, float(touch_threshold), C.byref(st)))
+    A, S, n, dev = self.n_agents, self.stride, self.n_envs, self.device
+    self.episode_stats = {k: _alias(getattr(st, k), (A, S), '<f8', dev)[:, :n] for k in ('ep_return', 'last_return')}
+    self.episode_stats.update({k: _alias(getattr(st, k), (S,), '<i4', dev)[:n]
+                               for k in ('ep_goal_touches', 'ep_len', 'last_goal_touches', 'last_len', 'ep_count')})
+    return self.episode_stats
+
   # ---- lifetime -----------------------------------------------------------------------------
   def close(self):
     if getattr(self, 'h', None) is not None and self.h:

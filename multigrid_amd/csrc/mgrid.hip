@@ -1150,6 +1150,58 @@ void vis_hook(const uint64_t* patterns, int64_t n, uint64_t* out) {
   }
 }
 
+
+// Episode statistics (mg_enable_episode_stats): what run_episode keeps beside the trajectories (v8_robust_ppo.py:234-235,
+// 246-248, 266, 273) — per-agent return of the episode in progress, its goal touches (rewards >= threshold), its length — and,
+// when the step reports done, the finished episode's figures and the episode count.  One thread per env; K > 1 walks the K
+// steps of a fused rollout's trajectory.  Additions happen per env in step order, so the sums are the reference's floats.
+struct EpStats {
+  double* ep_return; uint32_t* ep_goal_touches; uint32_t* ep_len;
+  double* last_return; uint32_t* last_goal_touches; uint32_t* last_len; uint32_t* ep_count;
+};
+
+template <typename R>
+__global__ void ep_stats_kernel(EpStats st, const R* __restrict__ reward, const uint8_t* __restrict__ dd, int dd_bytes, int A, int K,
+                                int64_t n_envs, int64_t stride, double thr, const uint8_t* __restrict__ reset_mask, int is_reset) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_envs) return;
+  if (is_reset) {                                 // env.reset(): the episode in progress is dropped (v8:224-235)
+    if (reset_mask && !reset_mask[n]) return;
+    for (int a = 0; a < A; ++a) st.ep_return[a * stride + n] = 0.0;
+    st.ep_goal_touches[n] = 0; st.ep_len[n] = 0;
+    return;
+  }
+  constexpr int kMaxA = 5;                         // the largest n_agents any kernel here is instantiated for
+  double ret[kMaxA];
+#pragma unroll
+  for (int a = 0; a < kMaxA; ++a) ret[a] = a < A ? st.ep_return[a * stride + n] : 0.0;
+  uint32_t touches = st.ep_goal_touches[n], len = st.ep_len[n], count = st.ep_count[n];
+  bool finished = false;
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int a = 0; a < kMaxA; ++a)
+      if (a < A) {
+        const double r = (double)reward[((int64_t)k * A + a) * stride + n];
+        ret[a] += r;
+        touches += (r >= thr) ? 1u : 0u;
+      }
+    len += 1;
+    if (dd[((int64_t)k * stride + n) * dd_bytes + A]) {
+#pragma unroll
+      for (int a = 0; a < kMaxA; ++a)
+        if (a < A) { st.last_return[a * stride + n] = ret[a]; ret[a] = 0.0; }
+      st.last_goal_touches[n] = touches; st.last_len[n] = len;
+      count += 1; finished = true;
+      touches = 0; len = 0;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < kMaxA; ++a)
+    if (a < A) st.ep_return[a * stride + n] = ret[a];
+  st.ep_goal_touches[n] = touches; st.ep_len[n] = len;
+  if (finished) st.ep_count[n] = count;
+}
+
 }  // namespace
 
 struct mg_handle {
@@ -1188,6 +1240,7 @@ struct mg_handle {
   int fixed_mode; uint64_t fixed_pd; uint32_t fixed_pd_hi;       // mg_set_fixed_spawn
   std::vector<uint8_t> free_cells;         // host copy: cell (y*W + x) holds nothing (placement checks)
   int LW, LH;            // dims of the mutable-grid kernel's relative distance LUT
+  bool ep_on; double ep_thr; EpStats ep;   // mg_enable_episode_stats
   mg_buffers buf;
   std::vector<void*> allocs;
 };
@@ -1310,6 +1363,24 @@ void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* l
   *lds_out = lds;
 }
 
+// After a reset / step / rollout launch: fold its rewards and done flags into the episode statistics (same stream).
+int launch_ep_stats(mg_handle* h, int op, const uint8_t* mask, int n_roll, const mg_rollout_out* roll) {
+  if (!h->ep_on) return MG_OK;
+  const mg_config& c = h->cfg;
+  const void* rw = n_roll > 0 ? (const void*)roll->reward : (const void*)h->buf.reward;
+  const uint8_t* dd = n_roll > 0 ? roll->dir_done : h->buf.dir_done;
+  const int K = n_roll > 0 ? n_roll : 1;
+  const unsigned blocks = (unsigned)((c.n_envs + 255) / 256);
+  if (c.reward_dtype == MG_REWARD_F32)
+    hipLaunchKernelGGL(ep_stats_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, h->ep, (const float*)rw, dd, h->dd_bytes,
+                       c.n_agents, K, c.n_envs, h->stride, h->ep_thr, mask, op == OP_RESET ? 1 : 0);
+  else
+    hipLaunchKernelGGL(ep_stats_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, h->ep, (const double*)rw, dd, h->dd_bytes,
+                       c.n_agents, K, c.n_envs, h->stride, h->ep_thr, mask, op == OP_RESET ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+
 int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, const int8_t* respawn,
            const int8_t* reset_spawn, const uint8_t* mask, int random_actions, uint8_t* actions_out,
            const int8_t* objdrop = nullptr, const int8_t* reset_gen = nullptr, const int8_t* scatter = nullptr,
@@ -1354,7 +1425,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     hipLaunchKernelGGL(h->dvar->fn, dim3(grid), dim3(nw * kWave), lds, h->stream, p);
     HIP_TRY(hipGetLastError());
     if (op == OP_RESET) h->reset_epoch += 1;
-    return MG_OK;
+    return launch_ep_stats(h, op, mask, 0, nullptr);
   }
   if (objdrop || reset_gen || scatter) return fail(MG_EINVAL, "objdrop / gen / scatter injection needs a mutable-grid handle");
   if (n_roll > 0) {
@@ -1374,7 +1445,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     }
     hipLaunchKernelGGL(h->var->roll[rt ? 1 : 0], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
     HIP_TRY(hipGetLastError());
-    return MG_OK;
+    return launch_ep_stats(h, op, mask, n_roll, roll);
   }
   const bool table = launch_uses_table(h);
   launch_geometry(h, table, &nw, &grid, &lds);
@@ -1382,7 +1453,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   hipLaunchKernelGGL(table ? h->var->table[fast] : h->var->generic[fast], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
   HIP_TRY(hipGetLastError());
   if (op == OP_RESET) h->reset_epoch += 1;
-  return MG_OK;
+  return launch_ep_stats(h, op, mask, 0, nullptr);
 }
 
 // Switch the handle to the mutable-grid kernel: allocate the per-env grids and carry words (once),
@@ -1497,6 +1568,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   h->dynamic = false; h->dvar = dvar; h->GW = (c.width * c.height + 3) / 4;
   h->base_grid = nullptr; h->grid0 = nullptr; h->per_env_maps = false; h->carry = nullptr; h->grid = nullptr; h->aux = nullptr; h->obs_full = nullptr;
   h->full_obs = c.env_kind == MG_KIND_MEETUP; h->LW = c.width; h->LH = c.height;
+  h->ep_on = false; h->ep_thr = 0.0; memset(&h->ep, 0, sizeof(h->ep));
   h->dyn_waves_cu = 8; h->fixed_mode = 0; h->fixed_pd = 0; h->fixed_pd_hi = 0;
   if (dvar) {
     hipFuncAttributes fa;
@@ -1964,6 +2036,29 @@ int mg_rollout_random(mg_handle* h, int32_t n_steps, const mg_rollout_out* out) 
   int rc = launch(h, OP_STEP, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, n_steps, out);
   if (rc == MG_OK) h->t += (uint64_t)n_steps;
   return rc;
+}
+
+int mg_enable_episode_stats(mg_handle* h, double touch_threshold, mg_episode_stats* out) {
+  if (!h || !out) return fail(MG_EINVAL, "null argument");
+  if (h->cfg.n_agents > 5) return fail(MG_EUNSUPPORTED, "episode statistics cover up to five agents");
+  DeviceGuard g(h->device);
+  if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
+  if (!h->ep.ep_return) {
+    const size_t S = (size_t)h->stride, A = (size_t)h->cfg.n_agents;
+    int rc = dalloc(h, &h->ep.ep_return, A * S);
+    if (rc == MG_OK) rc = dalloc(h, &h->ep.last_return, A * S);
+    if (rc == MG_OK) rc = dalloc(h, &h->ep.ep_goal_touches, S);
+    if (rc == MG_OK) rc = dalloc(h, &h->ep.ep_len, S);
+    if (rc == MG_OK) rc = dalloc(h, &h->ep.last_goal_touches, S);
+    if (rc == MG_OK) rc = dalloc(h, &h->ep.last_len, S);
+    if (rc == MG_OK) rc = dalloc(h, &h->ep.ep_count, S);
+    if (rc != MG_OK) { memset(&h->ep, 0, sizeof(h->ep)); return rc; }
+  }
+  h->ep_on = true; h->ep_thr = touch_threshold;
+  out->ep_return = h->ep.ep_return; out->ep_goal_touches = h->ep.ep_goal_touches; out->ep_len = h->ep.ep_len;
+  out->last_return = h->ep.last_return; out->last_goal_touches = h->ep.last_goal_touches; out->last_len = h->ep.last_len;
+  out->ep_count = h->ep.ep_count;
+  return MG_OK;
 }
 
 int mg_get_buffers(mg_handle* h, mg_buffers* out) {

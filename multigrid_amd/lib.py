@@ -53,6 +53,11 @@ class MgBuffers(C.Structure):
   ]
 
 
+class MgEpisodeStats(C.Structure):
+  _fields_ = [('ep_return', C.c_void_p), ('ep_goal_touches', C.c_void_p), ('ep_len', C.c_void_p), ('last_return', C.c_void_p),
+              ('last_goal_touches', C.c_void_p), ('last_len', C.c_void_p), ('ep_count', C.c_void_p)]
+
+
 class MgRolloutOut(C.Structure):
   _fields_ = [('obs_image', C.c_void_p), ('reward', C.c_void_p), ('dir_done', C.c_void_p), ('actions', C.c_void_p)]
 
@@ -74,6 +79,7 @@ SYMBOLS = {
     'mg_export_grid': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_step_random': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_rollout_random': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(MgRolloutOut)]),
+    'mg_enable_episode_stats': (C.c_int, [C.c_void_p, C.c_double, C.POINTER(MgEpisodeStats)]),
     'mg_get_buffers': (C.c_int, [C.c_void_p, C.POINTER(MgBuffers)]),
     'mg_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_get_stream': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
