@@ -358,6 +358,12 @@ typedef struct mg_rollout_out {
 } mg_rollout_out;
 int mg_rollout_random(mg_handle* h, int32_t n_steps, const mg_rollout_out* out);
 
+/* The same fused rollout with the CALLER's actions: step k takes slot k of `actions`, device uint8
+ * [n_steps][env_stride][MG_SLOTS(A)] laid out like mg_step's (the loop env.step(actions_k) for k in range(K) over a recorded or
+ * open-loop action sequence, v8_robust_ppo.py:237-239); order and respawn draws stay on the device (free-running).  The handle ends
+ * exactly where n_steps calls of mg_step would have left it.  out->actions is not written.  actions == NULL: mg_rollout_random. */
+int mg_rollout(mg_handle* h, int32_t n_steps, const void* actions, const mg_rollout_out* out);
+
 int mg_get_buffers(mg_handle* h, mg_buffers* out);
 
 /* Stream control: by default the handle owns a stream; mg_set_stream adopts the caller's

@@ -311,6 +311,31 @@ class BatchedMultiGrid:
     _lib.check(self.L.mg_rollout_random(self.h, K, C.byref(ro)))
     return out
 
+  def rollout(self, actions, out=None):
+    """len(actions) fused steps with the caller's actions in one launch (mg_rollout): actions uint8 [K, N, A], or already in
+    the device layout [K, stride, slots]; step k takes actions[k].  Same trajectory dict as rollout_random ('actions' = None)."""
+    a = torch.as_tensor(actions, device=self.device)
+    K = int(a.shape[0])
+    if tuple(a.shape[1:]) != (self.stride, self.slots) or a.dtype != torch.uint8 or not a.is_contiguous():
+      assert tuple(a.shape[1:]) == (self.n_envs, self.n_agents), tuple(a.shape)
+      ring = torch.full((K, self.stride, self.slots), 6, dtype=torch.uint8, device=self.device)
+      ring[:, :self.n_envs, :self.n_agents] = a.to(torch.uint8)
+      a = ring
+    if out is None or out['_K'] != K or out['_act'] is not None:
+      out = None
+    S, A, V, n, dev = self.stride, self.n_agents, self.view_size, self.n_envs, self.device
+    if out is None:
+      ddb = self._dir_done.shape[1]
+      out = {'_K': K, '_obs': torch.empty((K, A, S, V, V, 3), dtype=torch.uint8, device=dev),
+             '_reward': torch.empty((K, A, S), dtype=self._reward.dtype, device=dev),
+             '_dd': torch.empty((K, S, ddb), dtype=torch.uint8, device=dev), '_act': None}
+      out.update(image=out['_obs'][:, :, :n], reward=out['_reward'][:, :, :n], direction=out['_dd'][:, :n, :A].permute(0, 2, 1),
+                 done=out['_dd'][:, :n, A], actions=None)
+    ro = _lib.MgRolloutOut(out['_obs'].data_ptr(), out['_reward'].data_ptr(), out['_dd'].data_ptr(), None)
+    _lib.check(self.L.mg_rollout(self.h, K, C.c_void_p(a.data_ptr()), C.byref(ro)))
+    out['_ring'] = a            # keep the ring alive until the launch that reads it has been ordered behind later work
+    return out
+
   def sync(self):
     _lib.check(self.L.mg_sync(self.h))
 

@@ -606,7 +606,12 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
   const uint32_t* const inj_spawn = FAST ? nullptr : p.reset_spawn;
   if (is_step) {
     // ---- actions -------------------------------------------------------------------------
-    if (ROLL || (!FAST && p.random_actions)) actw = draw_actions<A>(p, n, gid, active);
+    if (ROLL && p.actions) {                   // mg_rollout with the caller's action ring: step k's slot, decoded as mg_step does
+      const uint32_t w = p.actions[n * kSlotWords<A>], w2 = A > 4 ? p.actions[n * kSlotWords<A> + 1] : 0u;
+      actw = 0;
+#pragma unroll
+      for (int a = 0; a < A; ++a) actw |= min(((a < 4 ? w >> (8 * a) : w2 >> (8 * (a - 4)))) & 255u, 7u) << (3 * a);
+    } else if (ROLL || (!FAST && p.random_actions)) actw = draw_actions<A>(p, n, gid, active);
     // ---- step_count += 1 (multigrid.py:968) ----------------------------------------------
     uint32_t step = (st & 0xFFFFu) + 1u;
     uint32_t dbits = st >> 16;
@@ -954,6 +959,7 @@ __global__ __launch_bounds__(kMaxBlock) void mg_rollout_kernel(const Params p) {
       q.reward = reinterpret_cast<double*>(reinterpret_cast<char*>(p.traj_reward) + k * slot_rew * (p.reward_f32 ? 4 : 8));
       q.dir_done = p.traj_dd + k * slot_dd;
       q.actions_out = p.traj_actions ? p.traj_actions + k * slot_act : nullptr;
+      q.actions = p.actions ? p.actions + k * slot_act : nullptr;
 #pragma unroll 1
       for (int jj = 0; jj < nj; ++jj) {
         step_chunk<A, V, TAB, true, true>(q, map, dist, table, cidx, stage, lane, (g0 + jj * cstride) * kWave, s0.pd, s0.shw, s0.st,
@@ -2026,14 +2032,16 @@ int mg_debug_device_sqrt(int device, int32_t n, double* out) {
   return MG_OK;
 }
 
-int mg_rollout_random(mg_handle* h, int32_t n_steps, const mg_rollout_out* out) {
+int mg_rollout_random(mg_handle* h, int32_t n_steps, const mg_rollout_out* out) { return mg_rollout(h, n_steps, nullptr, out); }
+
+int mg_rollout(mg_handle* h, int32_t n_steps, const void* actions, const mg_rollout_out* out) {
   if (!h || !out) return fail(MG_EINVAL, "null argument");
   if (n_steps < 1 || n_steps > 65535) return fail(MG_EINVAL, "n_steps must be in [1,65535]");
   if (!out->obs_image || !out->reward || !out->dir_done) return fail(MG_EINVAL, "obs_image, reward and dir_done of mg_rollout_out must be set");
-  if (h->dynamic) return fail(MG_EUNSUPPORTED, "mg_rollout_random runs the shared-map kernels (static layouts of empty/wall/goal/lava cells)");
-  if (h->buf.env_reward) return fail(MG_EUNSUPPORTED, "mg_rollout_random has no env_reward output (emit_env_reward = 0)");
-  if (!h->have_reset) return fail(MG_ESTATE, "mg_reset must be called before mg_rollout_random");
-  int rc = launch(h, OP_STEP, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, n_steps, out);
+  if (h->dynamic) return fail(MG_EUNSUPPORTED, "mg_rollout / mg_rollout_random run the shared-map kernels (static layouts of empty/wall/goal/lava cells)");
+  if (h->buf.env_reward) return fail(MG_EUNSUPPORTED, "mg_rollout / mg_rollout_random have no env_reward output (emit_env_reward = 0)");
+  if (!h->have_reset) return fail(MG_ESTATE, "mg_reset must be called before mg_rollout / mg_rollout_random");
+  int rc = launch(h, OP_STEP, actions, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, n_steps, out);
   if (rc == MG_OK) h->t += (uint64_t)n_steps;
   return rc;
 }

@@ -79,6 +79,7 @@ SYMBOLS = {
     'mg_export_grid': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_step_random': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mg_rollout_random': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(MgRolloutOut)]),
+    'mg_rollout': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(MgRolloutOut)]),
     'mg_enable_episode_stats': (C.c_int, [C.c_void_p, C.c_double, C.POINTER(MgEpisodeStats)]),
     'mg_get_buffers': (C.c_int, [C.c_void_p, C.POINTER(MgBuffers)]),
     'mg_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -116,3 +116,47 @@ def test_rollout_refusals(cluttered_cells, playground_cells):
   with pytest.raises(lib.MgError, match='env_reward'):
     env.rollout_random(4)
   env.close()
+
+
+@pytest.mark.parametrize('path', ['generic', 'table'])
+def test_rollout_with_caller_actions(cluttered_cells, monkeypatch, path):
+  """mg_rollout: K fused steps taking the caller's action ring, against K mg_step launches on a twin handle and against the
+  oracle stepping with the same actions (order and respawn draws free-running on both sides)."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  monkeypatch.setenv('MG_DEBUG_ROLL_PATH', {'generic': '1', 'table': '2'}[path])
+  kp = 'table' if path == 'table' else 'auto'
+  n, K = 3000, 41
+  env = BatchedMultiGrid(cluttered_cells, n_envs=n, seed=9, max_steps=30, kernel_path=kp)
+  twin = BatchedMultiGrid(cluttered_cells, n_envs=n, seed=9, max_steps=30, kernel_path=kp)
+  orc = c_oracle.OracleBatch(cluttered_cells, n, max_steps=30, shaping=1, auto_reset=1, seed=9)
+  env.reset(); twin.reset(); orc.reset()
+  g = torch.Generator(device='cpu').manual_seed(4)
+  traj = None
+  for call in range(2):
+    acts = torch.randint(0, 7, (K, n, 3), dtype=torch.uint8, generator=g)
+    acts[:, :, 0] = torch.where(torch.rand((K, n), generator=g) < 0.5, torch.tensor(2, dtype=torch.uint8), acts[:, :, 0])   # more forward moves
+    traj = env.rollout(acts.to(env.device), out=traj)
+    assert traj['actions'] is None and env.step_index == (call + 1) * K
+    img = traj['image'].cpu().numpy().reshape(K, 3, n, -1)
+    rew = traj['reward'].cpu().numpy()
+    done = traj['done'].cpu().numpy()
+    for k in range(K):
+      w = 'call %d step %d' % (call, k)
+      twin.step(acts[k].t().contiguous().to(twin.device))       # step() takes agent-major [A, N]
+      oa = np.full((3, orc.stride), 6, np.uint8)                 # the oracle takes agent-major actions too
+      oa[:, :n] = acts[k].numpy().T
+      orc.step(oa)
+      assert np.array_equal(img[k], twin.obs_image.cpu().numpy().reshape(3, n, -1)), w
+      assert np.array_equal(rew[k].view(np.int64), twin.reward.cpu().numpy().view(np.int64)), w
+      assert np.array_equal(img[k], orc.obs_image[:, :n]), w + ' vs oracle'
+      assert np.array_equal(rew[k].view(np.int64), orc.reward[:, :n].view(np.int64)), w + ' vs oracle'
+      assert np.array_equal(done[k], orc.done[:n]), w
+    assert torch.equal(env._env_state[:n], twin._env_state[:n])
+  assert env.check_errors() == 0
+  # an action outside [0, 6] in the ring is flagged like mg_step's (multigrid.py:902)
+  bad = torch.full((2, n, 3), 9, dtype=torch.uint8)
+  env.rollout(bad.to(env.device))
+  from multigrid_amd import lib
+  assert env.check_errors() & lib.ERR_BAD_ACTION
+  env.close(); twin.close()
