@@ -137,6 +137,7 @@ __device__ __forceinline__ int clamp_ring(int v, int hi) {
 // by clamping each coordinate onto the ring; the own cell shows the carried object (:1029-1033).
 // Exactly one of (r.x, f.x) and one of (r.y, f.y) is non-zero, so the clamped coordinates separate:
 // offset(vx, vy) = U[vx] + Vv[vy] with 2V precomputed terms.
+__device__ __forceinline__ int lane_of(const uint8_t*) { return (int)(threadIdx.x & 63u); }
 template <int V>
 __device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, const uint32_t* lut, uint32_t me, uint32_t ck,
                                          uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t& vm) {
@@ -165,7 +166,11 @@ __device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, cons
   // three passes, each over all cells, so that the two dependent LDS reads of a cell (kind byte, then its LUT word)
   // are in flight for many cells at once instead of a handful (two waves per SIMD do not hide the round trips)
 #pragma unroll
+#if MG_ABL == 6   // timing-only: the same 49 byte gathers, every lane on its own bank (wrong images) — what a conflict-free layout could buy
+  for (int c = 0; c < V * V; ++c) code[c] = (g - (lane_of(g)))[(lane_of(g) << 2) + ((U[c / V] + Vv[c % V]) & 0x0F03)];
+#else
   for (int c = 0; c < V * V; ++c) code[c] = g_get(g, U[c / V] + Vv[c % V]);
+#endif
 #if MG_VIEW_PHASES
   __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -721,7 +726,7 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up t
   uint32_t err = 0;
   // vector-memory operations a chunk issues after the next chunk's prefetch, all of them for at
   // least one lane: obs stores, env_state, carry, dir_done (rewards in a step and dirty grid rows on top)
-#if MG_ABL == 0
+#if MG_ABL == 0 || MG_ABL == 6
   constexpr int kObs = A * ((4 * ROWB + kWave - 1) / kWave);
 #else
   constexpr int kObs = 0;
