@@ -517,7 +517,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 #pragma unroll
     for (int a = 0; a < A; ++a) {
       out_rew[a] = rew[a];
-      if (p.shaping != MG_SHAPING_NONE) {
+      if (p.shaping != MG_SHAPING_NONE && MG_ABL != 4) {
         // get_goal_position (v8:159-169): the per-env scattered goal of a Cluttered layout, else the handle's
         const bool own = (p.kind == MG_KIND_CLUTTERED && p.n_goals != 0) || p.kind == MG_KIND_FOURROOMS || p.grid0 != nullptr;
         const int gx = own ? (int)(goal[0] & 63u) : p.gx, gy = own ? (int)((goal[0] >> 6) & 63u) : p.gy;
@@ -678,7 +678,12 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     for (int a = 0; a < A; ++a) {
       uint32_t s[NW + 1];
       uint64_t vm;
+#if MG_ABL == 7   // timing-only: no view computation, the staging and the stores of (meaningless) images stay
+      for (int i = 0; i <= NW; ++i) s[i] = pd_get(pd, a) + (uint32_t)i;
+      vm = ~0ull;
+#else
       dyn_view<V>(p, g, lut, pd_get(pd, a), (uint32_t)(carry >> (8 * a)) & 255u, s, vm);
+#endif
       emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB, ((p.nt_obs >> a) & 1) != 0);
     }
   }
@@ -726,7 +731,7 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up t
   uint32_t err = 0;
   // vector-memory operations a chunk issues after the next chunk's prefetch, all of them for at
   // least one lane: obs stores, env_state, carry, dir_done (rewards in a step and dirty grid rows on top)
-#if MG_ABL == 0 || MG_ABL == 6
+#if MG_ABL == 0 || MG_ABL >= 3
   constexpr int kObs = A * ((4 * ROWB + kWave - 1) / kWave);
 #else
   constexpr int kObs = 0;
