@@ -745,7 +745,7 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
   // ---- gen_obs (multigrid.py:1037-1067) -----------------------------------------------------
 #if MG_ABL != 2
 #pragma unroll
-  for (int a = 0; a < A; ++a) {
+  for (int a = 0; a < (MG_ABL == 8 ? 1 : A); ++a) {   // (8: timing-only, one agent's view per wave — what splitting the agents over waves could buy)
     uint32_t s[NW + 1];
     uint64_t vm;
     if (TAB) table_view<V>(p, table, cidx, pd_get(pd, a), s, vm);
