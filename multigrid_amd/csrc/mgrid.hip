@@ -1444,6 +1444,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     p.traj_obs = roll->obs_image; p.traj_reward = roll->reward; p.traj_dd = roll->dir_done;
     p.traj_actions = reinterpret_cast<uint32_t*>(roll->actions);
     p.nt_obs = 0xFF; p.random_actions = 1;
+    if (const char* e = debug_env("MG_DEBUG_NT")) p.nt_obs = atoi(e);   // tuning experiments only
     launch_geometry(h, rt, &nw, &grid, &lds);
     if (!rt) {                                   // persistent on the generic path too: up to four chunks per wave, stepped together
       const int per_cu = std::max(1, std::min((int)((size_t)kLdsLimit / lds), 32 / nw));
