@@ -348,8 +348,10 @@ int mg_step_noalloc(const mg_config* cfg, int device, void* hip_stream, uint64_t
  *   obs_image uint8 [n_steps][A][env_stride][V*V*3]     reward double [n_steps][A][env_stride]
  *   dir_done  uint8 [n_steps][env_stride][dir_done_bytes]   actions uint8 [n_steps][env_stride][MG_SLOTS(A)] (may be NULL)
  * Afterwards the handle is exactly where n_steps calls of mg_step_random would have left it: env_state, step index, and
- * its own obs_image / reward / dir_done buffers hold the last step.  Shared-map handles without env_reward output only
- * (MG_EUNSUPPORTED otherwise); auto-reset and shaping as configured. */
+ * its own obs_image / reward / dir_done buffers hold the last step.  Handles without env_reward output only (MG_EUNSUPPORTED
+ * otherwise); auto-reset and shaping as configured.  Mutable-grid handles (DoorKey, Meetup, drawn layouts, layouts with objects,
+ * mg_set_maps) take the same call with the same result but run it as n_steps launches of their step kernel, each writing into its
+ * slot — there is no fused kernel for them; fully observed kinds: obs_image is uint8 [n_steps][env_stride][W*H*3] (mg_buffers.obs_full). */
 typedef struct mg_rollout_out {
   uint8_t* obs_image;
   double*  reward;

@@ -293,19 +293,26 @@ class BatchedMultiGrid:
     _lib.check(self.L.mg_step_random(self.h, ptr))
     return self.obs(), self.reward, self.done, {}
 
+  def _trajectory(self, K, store_actions):
+    """Caller-owned [K][...] trajectory buffers of a rollout in the library's layouts, plus the [:n_envs] views."""
+    A, V, S, n, dev = self.n_agents, self.view_size, self.stride, self.n_envs, self.device
+    full = self._obs_full is not None                 # fully observed kinds: one whole-grid image per env, shared by the agents
+    out = {'_K': K, '_obs': torch.empty((K, S, self.width, self.height, 3) if full else (K, A, S, V, V, 3), dtype=torch.uint8, device=dev),
+           '_reward': torch.empty((K, A, S), dtype=self._reward.dtype, device=dev),
+           '_dd': torch.empty((K, S, self._dir_done.shape[1]), dtype=torch.uint8, device=dev),
+           '_act': torch.empty((K, S, self.slots), dtype=torch.uint8, device=dev) if store_actions else None}
+    out.update(image=out['_obs'][:, :n] if full else out['_obs'][:, :, :n], reward=out['_reward'][:, :, :n],
+               direction=out['_dd'][:, :n, :A].permute(0, 2, 1), done=out['_dd'][:, :n, A],
+               actions=None if out['_act'] is None else out['_act'][:, :n, :A])
+    return out
+
   def rollout_random(self, n_steps, out=None, store_actions=True):
     """n_steps fused steps with on-device uniform random actions in one launch (mg_rollout_random).  Returns the
     trajectory dict {'image' uint8[K, A, N, V, V, 3], 'direction' uint8[K, A, N] (view), 'reward' float64[K, A, N],
     'done' uint8[K, N] (view), 'actions' uint8[K, N, A] (view) or None}; pass the dict back as `out` to reuse its buffers."""
-    K, A, V, S, n, dev = int(n_steps), self.n_agents, self.view_size, self.stride, self.n_envs, self.device
+    K = int(n_steps)
     if out is None or out['_K'] != K:
-      ddb = self._dir_done.shape[1]
-      out = {'_K': K, '_obs': torch.empty((K, A, S, V, V, 3), dtype=torch.uint8, device=dev),
-             '_reward': torch.empty((K, A, S), dtype=self._reward.dtype, device=dev),
-             '_dd': torch.empty((K, S, ddb), dtype=torch.uint8, device=dev),
-             '_act': torch.empty((K, S, self.slots), dtype=torch.uint8, device=dev) if store_actions else None}
-      out.update(image=out['_obs'][:, :, :n], reward=out['_reward'][:, :, :n], direction=out['_dd'][:, :n, :A].permute(0, 2, 1),
-                 done=out['_dd'][:, :n, A], actions=None if out['_act'] is None else out['_act'][:, :n, :A])
+      out = self._trajectory(K, store_actions)
     ro = _lib.MgRolloutOut(out['_obs'].data_ptr(), out['_reward'].data_ptr(), out['_dd'].data_ptr(),
                            out['_act'].data_ptr() if out['_act'] is not None else None)
     _lib.check(self.L.mg_rollout_random(self.h, K, C.byref(ro)))
@@ -322,15 +329,7 @@ class BatchedMultiGrid:
       ring[:, :self.n_envs, :self.n_agents] = a.to(torch.uint8)
       a = ring
     if out is None or out['_K'] != K or out['_act'] is not None:
-      out = None
-    S, A, V, n, dev = self.stride, self.n_agents, self.view_size, self.n_envs, self.device
-    if out is None:
-      ddb = self._dir_done.shape[1]
-      out = {'_K': K, '_obs': torch.empty((K, A, S, V, V, 3), dtype=torch.uint8, device=dev),
-             '_reward': torch.empty((K, A, S), dtype=self._reward.dtype, device=dev),
-             '_dd': torch.empty((K, S, ddb), dtype=torch.uint8, device=dev), '_act': None}
-      out.update(image=out['_obs'][:, :, :n], reward=out['_reward'][:, :, :n], direction=out['_dd'][:, :n, :A].permute(0, 2, 1),
-                 done=out['_dd'][:, :n, A], actions=None)
+      out = self._trajectory(K, False)
     ro = _lib.MgRolloutOut(out['_obs'].data_ptr(), out['_reward'].data_ptr(), out['_dd'].data_ptr(), None)
     _lib.check(self.L.mg_rollout(self.h, K, C.c_void_p(a.data_ptr()), C.byref(ro)))
     out['_ring'] = a            # keep the ring alive until the launch that reads it has been ordered behind later work

@@ -2039,9 +2039,42 @@ int mg_rollout(mg_handle* h, int32_t n_steps, const void* actions, const mg_roll
   if (!h || !out) return fail(MG_EINVAL, "null argument");
   if (n_steps < 1 || n_steps > 65535) return fail(MG_EINVAL, "n_steps must be in [1,65535]");
   if (!out->obs_image || !out->reward || !out->dir_done) return fail(MG_EINVAL, "obs_image, reward and dir_done of mg_rollout_out must be set");
-  if (h->dynamic) return fail(MG_EUNSUPPORTED, "mg_rollout / mg_rollout_random run the shared-map kernels (static layouts of empty/wall/goal/lava cells)");
   if (h->buf.env_reward) return fail(MG_EUNSUPPORTED, "mg_rollout / mg_rollout_random have no env_reward output (emit_env_reward = 0)");
   if (!h->have_reset) return fail(MG_ESTATE, "mg_reset must be called before mg_rollout / mg_rollout_random");
+  if (h->dynamic) {
+    // Mutable-grid kinds have no fused kernel (their grids live in LDS for one step at a time): the same n_steps steps as n_steps
+    // launches of the step kernel, each writing straight into its trajectory slot; the last one writes the handle's own buffers,
+    // which are then copied into the last slot (same stream).  Same contract, one launch per step.
+    const mg_config& c = h->cfg;
+    const size_t S = (size_t)h->stride, A = (size_t)c.n_agents;
+    const size_t obs_b = h->full_obs ? S * c.width * c.height * 3 : A * S * c.view_size * c.view_size * 3;
+    const size_t rew_b = A * S * (c.reward_dtype == MG_REWARD_F32 ? 4 : 8), dd_b = S * h->dd_bytes, act_b = S * MG_SLOTS(c.n_agents);
+    const mg_buffers saved = h->buf;
+    uint8_t* const saved_full = h->obs_full;
+    int rc = MG_OK;
+    for (int32_t k = 0; k < n_steps && rc == MG_OK; ++k) {
+      if (k < n_steps - 1) {
+        if (h->full_obs) h->obs_full = out->obs_image + k * obs_b; else h->buf.obs_image = out->obs_image + k * obs_b;
+        h->buf.reward = reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(out->reward) + k * rew_b);
+        h->buf.dir_done = out->dir_done + k * dd_b;
+      } else {
+        h->buf = saved; h->obs_full = saved_full;
+      }
+      const uint8_t* act_k = actions ? static_cast<const uint8_t*>(actions) + k * act_b : nullptr;
+      uint8_t* act_out = (!actions && out->actions) ? out->actions + k * act_b : nullptr;
+      rc = launch(h, OP_STEP, act_k, nullptr, nullptr, nullptr, nullptr, actions ? 0 : 1, act_out);
+      if (rc == MG_OK) h->t += 1;
+    }
+    h->buf = saved; h->obs_full = saved_full;
+    if (rc != MG_OK) return rc;
+    DeviceGuard g(h->device);
+    if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
+    const size_t last = (size_t)n_steps - 1;
+    HIP_TRY(hipMemcpyAsync(out->obs_image + last * obs_b, h->full_obs ? h->obs_full : h->buf.obs_image, obs_b, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(reinterpret_cast<uint8_t*>(out->reward) + last * rew_b, h->buf.reward, rew_b, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(out->dir_done + last * dd_b, h->buf.dir_done, dd_b, hipMemcpyDeviceToDevice, h->stream));
+    return MG_OK;
+  }
   int rc = launch(h, OP_STEP, actions, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, n_steps, out);
   if (rc == MG_OK) h->t += (uint64_t)n_steps;
   return rc;

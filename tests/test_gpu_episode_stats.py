@@ -99,6 +99,25 @@ def test_mutable_grid_kind_and_caller_reset():
   env.close()
 
 
+def test_rollouts_of_a_mutable_grid_kind():
+  """Rollouts on a mutable-grid handle run as one launch per step into the trajectory slots: the statistics follow every slot."""
+  _need_gpu()
+  import multigrid_amd
+  n = 600
+  env = multigrid_amd.make_batched('MultiGrid-DoorKey-6x6-v0', n, seed=2, max_steps=20, shaping='v8')
+  st = env.enable_episode_stats(4.5)
+  ref = RefStats(env.n_agents, n, 4.5)
+  env.reset(); ref.reset()
+  for K in (25, 9):
+    traj = env.rollout_random(K)
+    r, d = traj['reward'].cpu().numpy(), traj['done'].cpu().numpy()
+    for k in range(K):
+      ref.step(r[k], d[k])
+    ref.check(st, 'doorkey rollout of %d' % K)
+  assert ref.count.min() >= 1 and env.check_errors() == 0
+  env.close()
+
+
 def test_matches_the_trajectory_form_used_by_training():
   """ppo.EpisodeStats (the vectorised trajectory form, §8) and the library's per-step form agree on the same rollout."""
   _need_gpu()

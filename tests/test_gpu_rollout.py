@@ -106,11 +106,6 @@ def test_rollout_refusals(cluttered_cells, playground_cells):
   with pytest.raises(lib.MgError, match='n_steps'):
     env.rollout_random(0)
   env.close()
-  env = BatchedMultiGrid(playground_cells, n_envs=64)
-  env.reset()
-  with pytest.raises(lib.MgError, match='shared-map'):
-    env.rollout_random(4)
-  env.close()
   env = BatchedMultiGrid(cluttered_cells, n_envs=64, emit_env_reward=True)
   env.reset()
   with pytest.raises(lib.MgError, match='env_reward'):
@@ -159,4 +154,50 @@ def test_rollout_with_caller_actions(cluttered_cells, monkeypatch, path):
   env.rollout(bad.to(env.device))
   from multigrid_amd import lib
   assert env.check_errors() & lib.ERR_BAD_ACTION
+  env.close(); twin.close()
+
+
+def _twin_check(env, twin, traj, k, A, n, w):
+  if env.obs_full is not None:
+    assert torch.equal(traj['image'][k], twin.obs_full), w + ' full obs'
+  else:
+    assert torch.equal(traj['image'][k], twin.obs_image), w + ' obs'
+  assert torch.equal(traj['reward'][k].view(torch.int64), twin.reward.view(torch.int64)), w + ' reward'
+  assert torch.equal(traj['direction'][k], twin.obs_dir) and torch.equal(traj['done'][k], twin.done), w + ' dir/done'
+
+
+@pytest.mark.parametrize('env_id,kw', [('MultiGrid-DoorKey-6x6-v0', dict(max_steps=40)), ('MultiGrid-Meetup-Empty-6x6-v0', dict(max_steps=30)),
+                                       ('MultiGrid-Cluttered-v0', dict(max_steps=25)), ('playground', {})])
+def test_rollout_on_mutable_grid_handles(playground_cells, env_id, kw):
+  """mg_rollout / mg_rollout_random on the mutable-grid kinds: same contract, run as one step-kernel launch per step — every slot
+  against a twin handle taking the same steps one call at a time, and the two handles' state afterwards."""
+  _need_gpu()
+  import multigrid_amd
+  from multigrid_amd.batched import BatchedMultiGrid
+  n, K = 700, 33
+  def mk():
+    if env_id == 'playground':
+      return BatchedMultiGrid(playground_cells, n_envs=n, seed=21, max_steps=30)
+    return multigrid_amd.make_batched(env_id, n, seed=21, **kw)
+  env, twin = mk(), mk()
+  assert env.mutable_grid
+  A = env.n_agents
+  env.reset(); twin.reset()
+  traj = None
+  for call in range(2):
+    traj = env.rollout_random(K, out=traj)
+    for k in range(K):
+      act_out = torch.zeros((twin.stride, twin.slots), dtype=torch.uint8, device=twin.device)
+      twin.step_random(act_out)
+      _twin_check(env, twin, traj, k, A, n, 'random call %d step %d' % (call, k))
+      assert torch.equal(traj['actions'][k], act_out[:n, :A])
+  g = torch.Generator(device='cpu').manual_seed(8)
+  acts = torch.randint(0, 7, (K, n, A), dtype=torch.uint8, generator=g)
+  traj2 = env.rollout(acts.to(env.device))
+  for k in range(K):
+    twin.step(acts[k].t().contiguous().to(twin.device))
+    _twin_check(env, twin, traj2, k, A, n, 'ring step %d' % k)
+  assert torch.equal(env._env_state[:n], twin._env_state[:n]) and torch.equal(env.carry, twin.carry)
+  assert torch.equal(env.grid_kinds(), twin.grid_kinds()) and env.step_index == twin.step_index == 3 * K
+  assert env.check_errors() == 0 and twin.check_errors() == 0
   env.close(); twin.close()
