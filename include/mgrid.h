@@ -226,7 +226,8 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells);
  * shaper goal is its own first goal cell (mg_buffers.aux word 0, bits 0..15), agents spawn anywhere.  Unknown cell types are
  * imported as walls and reported as MG_ERR_BAD_MAP (mg_check_errors), as are layouts with fewer free cells than agents.
  * MG_KIND_STATIC handles only; mg_reset is required afterwards; a later mg_set_static_map goes back to one shared layout.
- * mg_get_buffers must be called again afterwards (carry / grid / aux appear). */
+ * mg_get_buffers must be called again afterwards (carry / grid / aux appear).  cells is read by a kernel on the handle's stream:
+ * keep it alive and unchanged until that stream has passed the call (mg_sync). */
 int mg_set_maps(mg_handle* h, const uint8_t* cells);
 
 /* Episode statistics kept by the library: what run_episode keeps beside the trajectories (v8_robust_ppo.py:234-235, 246-248,
