@@ -175,7 +175,11 @@ __device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, cons
   __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
+#if MG_ABL == 9   // timing-only: no second, dependent LDS read per view cell (wrong images)
+  for (int c = 0; c < V * V; ++c) code[c] = code[c] * 0x00010101u;
+#else
   for (int c = 0; c < V * V; ++c) code[c] = lut[code[c]];
+#endif
 #if MG_VIEW_PHASES
   __builtin_amdgcn_sched_barrier(0);
 #endif
