@@ -359,13 +359,15 @@ def _random_layouts(rng, n, W, H, with_objects=True):
   return cells
 
 
-@pytest.mark.parametrize('W,H,A,V,objects', [(9, 9, 3, 5, True), (8, 7, 2, 7, True), (15, 15, 3, 5, False)])
-def test_per_env_maps_parity(W, H, A, V, objects):
+@pytest.mark.parametrize('W,H,A,V,objects,grid', [(9, 9, 3, 5, True, 0), (8, 7, 2, 7, True, 0), (15, 15, 3, 5, False, 0), (9, 9, 3, 5, True, 2)])
+def test_per_env_maps_parity(monkeypatch, W, H, A, V, objects, grid):
   """mg_set_maps: every env resets to its OWN layout (the batched form of N reference envs built on N different fixed maps)
   — free-running against the oracle holding the same N layouts, across auto-resets, with every env's own shaper goal."""
   _need_gpu()
   from multigrid_amd.batched import BatchedMultiGrid
   from multigrid_amd import layouts
+  if grid:      # few workgroups: every wave walks several chunks, so the per-env templates are read behind the prefetch of the next chunk
+    monkeypatch.setenv('MG_DEBUG_GRID', str(grid))
   n, max_steps = 700, 35
   rng = np.random.default_rng(W * 100 + H)
   cells = _random_layouts(rng, n, W, H, objects)
