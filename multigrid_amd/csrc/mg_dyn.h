@@ -177,6 +177,13 @@ __device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, cons
 #pragma unroll
 #if MG_ABL == 9   // timing-only: no second, dependent LDS read per view cell (wrong images)
   for (int c = 0; c < V * V; ++c) code[c] = code[c] * 0x00010101u;
+#elif MG_ABL == 10  // timing-only: the LUT read traded for an arithmetic decode (right for door-free, LavaWall-free grids only)
+  for (int c = 0; c < V * V; ++c) {
+    const uint32_t k = code[c], t = k >> 3;
+    uint32_t w = max(t | ((k & 7u) << 8), 1u);
+    w |= (t == (uint32_t)MG_T_WALL) ? F_OPAQUE : 0u;
+    code[c] = w;
+  }
 #else
   for (int c = 0; c < V * V; ++c) code[c] = lut[code[c]];
 #endif
