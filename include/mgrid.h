@@ -101,10 +101,12 @@ extern "C" {
                               gap is not drawn on grids with height < 7 */
 #define MG_MAX_SCATTER 64  /* gen_n_goals + gen_n_clutter */
 
-/* One-byte cell kind of the mutable per-env grids (mg_buffers.grid, carried objects):
- * 0 = nothing, door = 128 + color*4 + state, any other object = type*8 + color.  Agents are not
+/* One-byte cell kind of the mutable per-env grids, as the C ABI speaks it (mg_export_grid, mg_buffers.carry, injected
+ * layouts): 0 = nothing, door = 128 + color*4 + state, any other object = type*8 + color.  Agents are not
  * stored in the grid (their cells read 0): the reference keeps an Agent object in the cell, which
- * move_agent / agent_is_done always replace by None when the agent leaves (multigrid.py:817-847). */
+ * move_agent / agent_is_done always replace by None when the agent leaves (multigrid.py:817-847).
+ * (Inside the library the grids hold a bit-field form of these ids — opaque | type<<1 | colour<<5, csrc/mg_dyn.h — so that
+ * a view decodes a cell with one multiply; mg_buffers.grid is that raw storage, mg_export_grid translates.) */
 #define MG_KIND_ID(type, color, state) ((type) == MG_T_DOOR ? 128 + (color) * 4 + (state) : \
                                         ((type) <= MG_T_EMPTY || (type) == MG_T_AGENT) ? 0 : (type) * 8 + (color))
 
@@ -178,11 +180,13 @@ typedef struct mg_buffers {
                             (post-step, post-respawn position = what v8 reads as env.agent_pos[a], v8:242;
                             prev_x, prev_y, valid, stationary = v8 shaper state, v8:127-129, the count saturating at 7
                             because only "> 3" is ever tested, v8:202); word A = step_count | agent done bits<<16
-                            | (DOORKEY only) split_idx<<24, the width of the region agents (re)spawn in (doorkey.py:77-78) */
+                            | (DOORKEY only) split_idx<<24 (6 bits), the width of the region agents (re)spawn in
+                            (doorkey.py:77-78), and the low five bits of door_idx, the door's row (doorkey.py:58-61), in
+                            bits 21..23 (its bits 0..2) and 30..31 (its bits 3..4) */
   /* mutable-grid handles only (mutable_grid != 0), NULL / 0 otherwise: */
   uint32_t* carry;       /* [env_stride] (five agents: [env_stride][2]): byte a = kind id of the object agent a carries,
                             0 = nothing (multigrid.py:490, 926-951) */
-  uint32_t* grid;        /* bytes [env_stride/64][grid_words*4][64]: kind id of cell ci = y*W + x of env n at byte
+  uint32_t* grid;        /* bytes [env_stride/64][grid_words*4][64]: the library's cell code (see MG_KIND_ID) of cell ci = y*W + x of env n at byte
                             ((n/64)*grid_words*4 + ci)*64 + n%64 (cells >= W*H are padding).  Cell-major within a 64-env
                             chunk, so a wavefront moves its chunk between HBM and LDS as fully coalesced rows and a lane's
                             LDS address is linear in the cell index; use mg_export_grid for a plain [n][H*W] copy. */
@@ -403,6 +407,12 @@ int mg_debug_device_sqrt(int device, int32_t n, double* out);
  * exhaustively with the oracle's literal loops.  V in {3,5,7}; bit (i*V+j) of a pattern = view
  * cell (vx=i, vy=j) is opaque; `out` uses the same bit layout for "visible". */
 int mg_debug_vis_masks(int V, const uint64_t* patterns, int64_t n, uint64_t* out);
+
+/* Test hook, host only (no GPU call, no reference counterpart): how the mutable grids store public kind id `kind`
+ * (MG_KIND_ID): *code = the one-byte cell code, *kind_back = the id mg_export_grid turns it back into, *table_word =
+ * encode() triple (type | colour<<8 | state<<16) | behaviour flags<<24 as the kernels' table holds it, *decoded =
+ * type | colour<<8 as the views' arithmetic decode extracts it from the code. */
+int mg_debug_cell_code(int32_t kind, uint32_t* code, uint32_t* kind_back, uint32_t* table_word, uint32_t* decoded);
 
 const char* mg_last_error(void);
 const char* mg_version(void);

@@ -23,42 +23,87 @@ constexpr uint32_t F_OVERLAP = 1u << 28;   // can_overlap(): floor, open door (g
 constexpr uint32_t F_PICKUP = 1u << 29;    // can_pickup(): key, ball, box
 constexpr uint32_t F_DOOR = 1u << 30;
 constexpr uint32_t F_BOX = 1u << 24;
-constexpr uint32_t K_WALL = MG_T_WALL * 8 + 5;                 // grey wall: wall_rect and Grid.slice's padding
-constexpr uint32_t K_GOAL = MG_T_GOAL * 8 + 1;                 // green goal
-constexpr uint32_t K_DOOR_YELLOW_LOCKED = 128 + 4 * 4 + 2;     // Door('yellow', is_locked=True), doorkey.py:60
-constexpr uint32_t K_KEY_YELLOW = MG_T_KEY * 8 + 4;            // Key('yellow'), doorkey.py:65
-constexpr uint32_t K_DOOR_RED_LOCKED = 128 + 0 * 4 + 2;        // Door(color='red', is_locked=True), meetup.py:69
-constexpr uint32_t K_LAVA = MG_T_LAVA * 8 + 0;                 // red lava
-constexpr uint32_t K_LAVAWALL = MG_T_LAVA * 8 + 5;             // LavaWall (lava_walls.py:25-38)
-constexpr uint32_t K_AGENT0 = 224;                             // 224 + 4*agent + dir: LDS only, never stored to HBM
+
+// ---- cell codes ------------------------------------------------------------------------------------
+// The grids (HBM and LDS), the reset templates and the carry bytes in registers hold one-byte CELL CODES, a bit-field
+// form of the public kind ids (include/mgrid.h MG_KIND_ID, which the C ABI keeps speaking: mg_set_static_map /
+// mg_set_maps / mg_export_grid / mg_buffers.carry translate):
+//     code = X | T<<1 | C<<5      X = opaque (!see_behind()), T = encode() type (4 bits), C = encode() colour (3 bits)
+// so that a view cell's (type, colour, 0) bytes and its opacity bit come straight out of the byte with one 24-bit
+// multiply and one mask (dyn_view, DEC) instead of a second, dependent LDS read of a kind -> triple table — the
+// read the round-2 ablation priced at 15 % of the DoorKey kernel.  Eight bits hold type, colour and opacity of every
+// object; what does not fit is a door's closed / locked distinction, so:
+//     nothing (None)        T = 1 (what it encodes as: empty), X = 0                      = 2
+//     wall                  T = 2, X = 1;   LavaWall (looks like a grey wall, transparent, deadly): T = 2, C = 5, X = 0
+//     floor .. lava         T = type, X = 0
+//     door  open            T = 4, X = 0;   closed: T = 4, X = 1;   locked: T = 0, X = 1  (T = 0 is no object's type)
+//     agents (emit_full's temporary marks, LDS only)  T >= 12
+// Kernels that decode arithmetically (DEC) show a closed or locked door through an overlay, like an agent; layouts
+// whose doors cannot be tracked that way run the table-decoding instantiation (DEC = false) of the same code.
+__host__ __device__ constexpr uint32_t cell_code(uint32_t T, uint32_t C, uint32_t X) { return X | (T << 1) | (C << 5); }
+__host__ __device__ inline uint32_t code_T(uint32_t k) { return (k >> 1) & 15u; }
+__host__ __device__ inline uint32_t code_C(uint32_t k) { return (k >> 5) & 7u; }
+constexpr uint32_t K_NONE = cell_code(MG_T_EMPTY, 0, 0);       // grid.get(...) is None
+constexpr uint32_t K_WALL = cell_code(MG_T_WALL, 5, 1);        // grey wall: wall_rect and Grid.slice's padding
+constexpr uint32_t K_GOAL = cell_code(MG_T_GOAL, 1, 0);        // green goal
+constexpr uint32_t K_DOOR_YELLOW_LOCKED = cell_code(0, 4, 1);  // Door('yellow', is_locked=True), doorkey.py:60
+constexpr uint32_t K_KEY_YELLOW = cell_code(MG_T_KEY, 4, 0);   // Key('yellow'), doorkey.py:65
+constexpr uint32_t K_DOOR_RED_LOCKED = cell_code(0, 0, 1);     // Door(color='red', is_locked=True), meetup.py:69
+constexpr uint32_t K_LAVA = cell_code(MG_T_LAVA, 0, 0);        // red lava
+constexpr uint32_t K_LAVAWALL = cell_code(MG_T_WALL, 5, 0);    // LavaWall (lava_walls.py:25-38)
+// an agent marked into the LDS grid while a fully observed image is encoded (emit_full): T = 12 + (i >> 2), X | T's low
+// bits = i & 3 ... any 16 codes with T >= 12; here i = 4*agent + dir in bits 0..2 and 5
+__host__ __device__ constexpr uint32_t agent_mark(uint32_t i) { return 0x18u | (i & 7u) | ((i >> 3) << 5); }
 enum { P_GEN = 4, P_KEY = 5, P_OBJDROP = 6 };
 
-// kind id -> encode() triple (type | color<<8 | state<<16) + behaviour flags.  256 entries, built
-// once per workgroup into LDS.
+// public kind id (MG_KIND_ID) <-> cell code.  Unknown ids come back as walls, as the import always treated them.
+__host__ __device__ inline uint32_t code_from_kind(uint32_t p) {
+  if (p == 0u) return K_NONE;
+  if (p >= 128u) {
+    const uint32_t color = ((p - 128u) >> 2) & 7u, state = p & 3u;
+    return state == 0u ? cell_code(MG_T_DOOR, color, 0) : state == 1u ? cell_code(MG_T_DOOR, color, 1) : cell_code(0, color, 1);
+  }
+  const uint32_t type = p >> 3, color = p & 7u;
+  if (type == (uint32_t)MG_T_WALL) return cell_code(MG_T_WALL, color, 1);
+  if (type == (uint32_t)MG_T_LAVA && color == 5u) return K_LAVAWALL;
+  if (type < (uint32_t)MG_T_WALL || type > (uint32_t)MG_T_LAVA || type == (uint32_t)MG_T_DOOR) return K_WALL;
+  return cell_code(type, color, 0);
+}
+__host__ __device__ inline uint32_t kind_from_code(uint32_t k) {
+  const uint32_t X = k & 1u, T = code_T(k), C = code_C(k);
+  if (T == 0u) return X ? 128u + C * 4u + 2u : 0u;
+  if (T == (uint32_t)MG_T_EMPTY || T > (uint32_t)MG_T_LAVA) return 0u;
+  if (T == (uint32_t)MG_T_DOOR) return 128u + C * 4u + X;
+  if (T == (uint32_t)MG_T_WALL && !X) return (uint32_t)MG_T_LAVA * 8u + 5u;
+  return T * 8u + C;
+}
+// The carry word (one public kind id per byte; only keys, balls and boxes are ever carried, 0 = nothing) as cell codes
+// and back, all bytes at once: public = C | T<<3, code = T<<1 | C<<5.
+__device__ __forceinline__ uint32_t carry_to_codes(uint32_t p) { return ((p & 0x07070707u) << 5) | ((p & 0x78787878u) >> 2); }
+__device__ __forceinline__ uint32_t carry_to_kinds(uint32_t k) { return ((k >> 5) & 0x07070707u) | ((k << 2) & 0x78787878u); }
+
+// cell code -> encode() triple (type | color<<8 | state<<16) + behaviour flags.  256 entries, built
+// once per workgroup into LDS: the action phase reads it for the cell in front of an agent, the fully observed
+// images (emit_full) and the table-decoding views (DEC = false) for every cell.  door_state = what a non-open door
+// with T = 4 encodes as (1 = closed).
 __host__ __device__ inline uint32_t kind_word(uint32_t k) {
-  if (k == 0u) return (uint32_t)MG_T_EMPTY | F_FREE;
-  if (k >= K_AGENT0) {   // an agent marked into the LDS grid while a fully observed image is encoded (emit_full)
-    const uint32_t id = ((k - K_AGENT0) >> 2) & 3u, dir = k & 3u;
+  const uint32_t X = k & 1u, T = code_T(k), C = code_C(k);
+  if (T >= 12u) {        // emit_full's agent marks
+    const uint32_t i = (k & 7u) | ((k >> 5) << 3), id = (i >> 2) & 3u, dir = i & 3u;
     return (uint32_t)MG_T_AGENT | (id << 8) | (dir << 16);        // Agent.encode, multigrid.py:137-139
   }
-  if (k >= 128u) {
-    const uint32_t color = ((k - 128u) >> 2) & 7u, state = k & 3u;
-    uint32_t w = (uint32_t)MG_T_DOOR | (color << 8) | (state << 16) | F_DOOR;
-    w |= (state == 0u) ? F_OVERLAP : F_OPAQUE;                 // Door.can_overlap / see_behind = is_open
-    return w;
-  }
-  const uint32_t type = k >> 3, color = k & 7u;
-  uint32_t w = type | (color << 8);
-  switch (type) {
-    case MG_T_WALL: w |= F_OPAQUE; break;
+  if (T == 0u)           // locked door (is_locked: can_overlap / see_behind False), Door.encode state 2
+    return X ? ((uint32_t)MG_T_DOOR | (C << 8) | (2u << 16) | F_DOOR | F_OPAQUE) : ((uint32_t)MG_T_EMPTY | F_FREE);
+  uint32_t w = T | (C << 8);
+  switch (T) {
+    case MG_T_EMPTY: w = (uint32_t)MG_T_EMPTY | F_FREE; break;
+    case MG_T_WALL: w |= X ? F_OPAQUE : F_KILL; break;        // X = 0: LavaWall (lava_walls.py:25-38), deadly and transparent
     case MG_T_FLOOR: w |= F_OVERLAP; break;
+    case MG_T_DOOR: w |= F_DOOR | (X ? (F_OPAQUE | (1u << 16)) : F_OVERLAP); break;   // Door.can_overlap / see_behind = is_open
     case MG_T_KEY: case MG_T_BALL: w |= F_PICKUP; break;
     case MG_T_BOX: w |= F_PICKUP | F_BOX; break;
     case MG_T_GOAL: w |= F_KILL | F_GOAL; break;
-    case MG_T_LAVA:            // grey lava = LavaWall (lava_walls.py:25-38): deadly and transparent, encoded as a grey wall
-      if (color == 5u) w = (uint32_t)MG_T_WALL | (5u << 8);
-      w |= F_KILL;
-      break;
+    case MG_T_LAVA: w |= F_KILL; break;
     default: break;                                            // a solid, inert object
   }
   return w;
@@ -85,7 +130,7 @@ __device__ __forceinline__ void g_set(uint8_t* gl, int off, uint32_t k) { gl[off
 template <int A>
 __device__ __forceinline__ bool dyn_free(const Params& p, const uint8_t* g, pd_t<A> pd, uint32_t occ, int x, int y, int xmax) {
   if ((unsigned)x >= (unsigned)min(xmax, p.W) || (unsigned)y >= (unsigned)p.H) return false;
-  if (g_get(g, g_off(p, x, y)) != 0u) return false;
+  if (g_get(g, g_off(p, x, y)) != K_NONE) return false;
   const uint32_t pos = (uint32_t)x | ((uint32_t)y << 6);
   bool ok = true;
 #pragma unroll
@@ -138,7 +183,11 @@ __device__ __forceinline__ int clamp_ring(int v, int hi) {
 // Exactly one of (r.x, f.x) and one of (r.y, f.y) is non-zero, so the clamped coordinates separate:
 // offset(vx, vy) = U[vx] + Vv[vy] with 2V precomputed terms.
 __device__ __forceinline__ int lane_of(const uint8_t*) { return (int)(threadIdx.x & 63u); }
-template <int V>
+// DEC: a cell code k = X | T<<1 | C<<5 times kDecMul is k<<7 | k<<19 (the two copies share no bit), which has T in the
+// low nibble of byte 1 and C in the low bits of byte 3; kDecMask keeps exactly those, so the product is the cell's
+// (state = 0, type, 0, colour) bytes — what pack_view<V, true> picks its stream bytes from.
+constexpr uint32_t kDecMul = (1u << 7) | (1u << 19), kDecMask = 0x07000F00u;
+template <int V, bool DEC>
 __device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, const uint32_t* lut, uint32_t me, uint32_t ck,
                                          uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t& vm) {
   const int x = aw_x(me), y = aw_y(me), d = aw_d(me);
@@ -163,8 +212,8 @@ __device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, cons
   uint32_t opq[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) opq[j] = 0;
-  // three passes, each over all cells, so that the two dependent LDS reads of a cell (kind byte, then its LUT word)
-  // are in flight for many cells at once instead of a handful (two waves per SIMD do not hide the round trips)
+  // passes, each over all cells, so that the LDS reads of a view are in flight for many cells at once instead of a
+  // handful (two waves per SIMD do not hide the round trips)
 #pragma unroll
 #if MG_ABL == 6   // timing-only: the same 49 byte gathers, every lane on its own bank (wrong images) — what a conflict-free layout could buy
   for (int c = 0; c < V * V; ++c) code[c] = (g - (lane_of(g)))[(lane_of(g) << 2) + ((U[c / V] + Vv[c % V]) & 0x0F03)];
@@ -174,27 +223,36 @@ __device__ __forceinline__ void dyn_view(const Params& p, const uint8_t* g, cons
 #if MG_VIEW_PHASES
   __builtin_amdgcn_sched_barrier(0);
 #endif
+  if constexpr (DEC) {
+    // opacity = bit 0 of the code: {code, row} >> 1 shifts it in at the top, so walking vx upwards leaves bit vx of the
+    // row at 32 - V + vx; then the (type, colour) bytes by one multiply each — no second LDS read
+#pragma unroll
+    for (int vx = 0; vx < V; ++vx)
+#pragma unroll
+      for (int vy = 0; vy < V; ++vy) opq[vy] = __builtin_amdgcn_alignbit(code[vx * V + vy], opq[vy], 1);
+#pragma unroll
+    for (int vy = 0; vy < V; ++vy) opq[vy] >>= 32 - V;
+#pragma unroll
+    for (int c = 0; c < V * V; ++c) code[c] = __umul24(code[c], kDecMul);
+    // the own cell shows the carried object or None (multigrid.py:1029-1033)
+    pack_view<V, true>(code, opq, p.see_through != 0, __umul24(ck ? ck : K_NONE, kDecMul), s, vm);
+  } else {
+    // the second, dependent LDS read of every cell: code -> its table word
 #pragma unroll
 #if MG_ABL == 9   // timing-only: no second, dependent LDS read per view cell (wrong images)
-  for (int c = 0; c < V * V; ++c) code[c] = code[c] * 0x00010101u;
-#elif MG_ABL == 10  // timing-only: the LUT read traded for an arithmetic decode (right for door-free, LavaWall-free grids only)
-  for (int c = 0; c < V * V; ++c) {
-    const uint32_t k = code[c], t = k >> 3;
-    uint32_t w = max(t | ((k & 7u) << 8), 1u);
-    w |= (t == (uint32_t)MG_T_WALL) ? F_OPAQUE : 0u;
-    code[c] = w;
-  }
+    for (int c = 0; c < V * V; ++c) code[c] = code[c] * 0x00010101u;
 #else
-  for (int c = 0; c < V * V; ++c) code[c] = lut[code[c]];
+    for (int c = 0; c < V * V; ++c) code[c] = lut[code[c]];
 #endif
 #if MG_VIEW_PHASES
-  __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-  for (int vx = V - 1; vx >= 0; --vx)
+    for (int vx = V - 1; vx >= 0; --vx)
 #pragma unroll
-    for (int vy = 0; vy < V; ++vy) opq[vy] = view_row_bit(opq[vy], code[vx * V + vy]);
-  pack_view<V>(code, opq, p.see_through != 0, lut[ck] & 0xFFFFFFu, s, vm);
+      for (int vy = 0; vy < V; ++vy) opq[vy] = view_row_bit(opq[vy], code[vx * V + vy]);
+    pack_view<V, false>(code, opq, p.see_through != 0, lut[ck ? ck : K_NONE] & 0xFFFFFFu, s, vm);
+  }
 }
 
 // Inputs of one chunk, requested one chunk ahead with inline-asm loads and retired with a counted
@@ -305,7 +363,7 @@ __device__ __forceinline__ uint32_t meetup_dist(const Params& p, pd_t<A> pd, con
 // cell-major, so the wave gathers the 64 images straight into output order — lane l produces the
 // 16-byte vectors l, l+64, ... of the chunk's 64*W*H*3 contiguous bytes and every store instruction
 // writes 1 KB of contiguous bytes.  The agents are marked into the LDS grid for the duration (kinds
-// K_AGENT0 + 4*id + dir); the next chunk's copy-in overwrites every interior cell, so they never leak.
+// agent_mark(4*id + dir)); the next chunk's copy-in overwrites every interior cell, so they never leak.
 template <int A>
 __device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uint8_t* gwave, const uint32_t* lut,
                                           const uint16_t* cpc, pd_t<A> pd, int lane, uint8_t* gchunk) {
@@ -313,7 +371,7 @@ __device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uin
 #pragma unroll
   for (int b = 0; b < A; ++b) {
     const uint32_t o = pd_get(pd, b);
-    g_set(g, g_off(p, aw_x(o), aw_y(o)), K_AGENT0 + 4u * (uint32_t)b + (uint32_t)aw_d(o));
+    g_set(g, g_off(p, aw_x(o), aw_y(o)), agent_mark(4u * (uint32_t)b + (uint32_t)aw_d(o)));
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -363,7 +421,7 @@ __device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uin
 }
 
 // One chunk (64 envs) of one step()/reset() on mutable grids.
-template <int A, int V, bool FULL, int PRE>
+template <int A, int V, bool FULL, int PRE, bool DEC>
 __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, const uint32_t* lut, const uint32_t* base,
                                           const uint16_t* pidx, const uint16_t* cpc, uint32_t* stage, uint32_t* gw, int lane,
                                           int64_t env0, const DynIn<A, PRE>& in, uint32_t& err_acc) {
@@ -416,12 +474,16 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     shw[a] = w & ~AW_POSDIR;
   }
   uint32_t st = in.st[A];
-  carry_t<A> carry = in.carry;
-  if constexpr (A > 4) carry |= (uint64_t)in.carry2 << 32;
+  carry_t<A> carry = carry_to_codes(in.carry);                // HBM keeps public kind ids (mg_buffers.carry)
+  if constexpr (A > 4) carry |= (uint64_t)carry_to_codes(in.carry2) << 32;
   uint32_t goal[3] = {in.aux[0], in.aux[1], in.aux[2]};       // MEETUP: goal_pos[2k] | goal_pos[2k+1] << 16, each x | y<<6
   uint32_t past = in.aux[3];                                  // MEETUP: past_goal_dist, one byte per agent
   // agents (re)spawn at x < spawn_w: the DoorKey split (doorkey.py:77-78), the whole grid otherwise
   int spawn_w = p.kind != MG_KIND_DOORKEY ? p.W : (int)min((st >> 24) & 63u, (uint32_t)p.W);
+  // DoorKey also keeps its door's row (doorkey.py:58-61; the low five bits, split over the word's free bits 21..23 and
+  // 30..31): the door stands at (split_idx, door_idx), and a kernel that decodes cell codes arithmetically shows it,
+  // while it is closed or locked, through emit_obs' overlay
+  uint32_t dk_bits = p.kind == MG_KIND_DOORKEY ? (st & 0xFFE00000u) : 0u;
   uint32_t done_flag = 0;
 
   const bool is_step = p.op == OP_STEP;
@@ -478,13 +540,13 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
             err |= w >> 16;
           } else if (fl & (F_FREE | F_OVERLAP)) {                               // move_agent :834-847
             npd = fpos | ((uint32_t)d << 12);
-            if (fl & F_OVERLAP) gs(ci, 0u);      // the Agent object replaces what was there, for good
+            if (fl & F_OVERLAP) gs(ci, K_NONE);  // the Agent object replaces what was there, for good
           }
         }
       } else if (act == 3u) {                                                   // _pickup :926-938
         if ((fl & F_PICKUP) && ck == 0u) {
           carry |= (carry_t<A>)kf << (8 * a);
-          gs(ci, 0u);
+          gs(ci, K_NONE);
         }
       } else if (act == 4u) {                                                   // _drop :940-951
         if ((fl & F_FREE) && !blocked && ck != 0u) {
@@ -493,14 +555,13 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
         }
       } else if (act == 5u) {                                                   // _toggle :953-961
         if (fl & F_DOOR) {                                                      // Door.toggle :112-122
-          const uint32_t state = kf & 3u, color = ((kf - 128u) >> 2) & 7u;
-          if (state == 2u) {
-            if (ck < 128u && (ck >> 3) == (uint32_t)MG_T_KEY && (ck & 7u) == color) gs(ci, kf & ~3u);
+          if (code_T(kf) == 0u) {                                               // locked: opens for a key of its colour, which is kept
+            if (code_T(ck) == (uint32_t)MG_T_KEY && code_C(ck) == code_C(kf)) gs(ci, cell_code(MG_T_DOOR, code_C(kf), 0));
           } else {
-            gs(ci, kf ^ 1u);
+            gs(ci, kf ^ 1u);                                                    // is_open = not is_open: the X bit
           }
         } else if (fl & F_BOX) {
-          gs(ci, 0u);                                                     // Box.toggle: replaced by its (empty) contents
+          gs(ci, K_NONE);                                                 // Box.toggle: replaced by its (empty) contents
         }
       }
       if (act > 6u) err |= MG_ERR_BAD_ACTION;                                   // assert False :902
@@ -535,7 +596,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
         shw[a] = v8_shape<true>(p, dist, shw[a], pd_get(pd, a), (actw >> (3 * a)) & 7u, rew[a], out_rew[a], gx, gy);
       }
     }
-    st = step | (dbits << 16) | (p.kind == MG_KIND_DOORKEY ? (uint32_t)spawn_w << 24 : 0u);
+    st = step | (dbits << 16) | dk_bits;
     if (active) {
 #pragma unroll
       for (int a = 0; a < A; ++a) {
@@ -571,6 +632,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       if (split < 1 || split > p.W - 2 || door < 1 || door > p.H - 2) { err |= MG_ERR_BAD_RESPAWN; split = start; door = 1; }
       for (int j = 0; j < p.H; ++j) gs(g_off(p, split, j), K_WALL);       // vert_wall(split_idx, 0)
       spawn_w = split;
+      dk_bits = ((uint32_t)split << 24) | (((uint32_t)door & 7u) << 21) | ((((uint32_t)door >> 3) & 3u) << 30);
     }
     if (p.kind == MG_KIND_CLUTTERED || p.kind == MG_KIND_MEETUP) {
       // place_obj for every scattered object in draw order (cluttered.py:28-36, meetup.py:67-72): the
@@ -619,10 +681,10 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       }
       for (int y = 0; y < 2 * rh; ++y) gs(g_off(p, rw, y), K_WALL);
       if (!two) for (int x = 0; x < 2 * rw; ++x) gs(g_off(p, x, rh), K_WALL);
-      if (g0 < p.H - 1) gs(g_off(p, rw, g0), 0u);                               // x = rw is never <= 1 for W >= 6
-      if (!two && g1 > 1) gs(g_off(p, g1, rh), 0u);
-      if (!two && g2 < p.W - 1) gs(g_off(p, g2, rh), 0u);
-      if (low && g3 < p.H - 1) gs(g_off(p, rw, g3), 0u);
+      if (g0 < p.H - 1) gs(g_off(p, rw, g0), K_NONE);                               // x = rw is never <= 1 for W >= 6
+      if (!two && g1 > 1) gs(g_off(p, g1, rh), K_NONE);
+      if (!two && g2 < p.W - 1) gs(g_off(p, g2, rh), K_NONE);
+      if (low && g3 < p.H - 1) gs(g_off(p, rw, g3), K_NONE);
     }
 #pragma unroll 1
     for (int a = 0; a < A; ++a) {                                               // place_agent, in agent order
@@ -651,15 +713,15 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     }
 #pragma unroll
     for (int a = 0; a < A; ++a) shw[a] = 0u;
-    st = p.kind == MG_KIND_DOORKEY ? (uint32_t)spawn_w << 24 : 0u;
+    st = dk_bits;
   }
 
   if (active) {
 #pragma unroll
     for (int a = 0; a < A; ++a) p.env_state[n * (A + 1) + a] = shw[a] | pd_get(pd, a);
     p.env_state[n * (A + 1) + A] = st;
-    p.carry[n * kSlotWords<A>] = (uint32_t)carry;
-    if constexpr (A > 4) p.carry[n * kSlotWords<A> + 1] = (uint32_t)(carry >> 32);
+    p.carry[n * kSlotWords<A>] = carry_to_kinds((uint32_t)carry);
+    if constexpr (A > 4) p.carry[n * kSlotWords<A> + 1] = carry_to_kinds((uint32_t)(carry >> 32));
     if (p.aux) reinterpret_cast<uint4*>(p.aux)[n] = make_uint4(goal[0], goal[1], goal[2], past);
     uint64_t dd = (uint64_t)done_flag << (8 * A);
 #pragma unroll
@@ -685,6 +747,15 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   if (FULL) {
     emit_full<A>(p, g, reinterpret_cast<const uint8_t*>(gw), lut, cpc, pd, lane, p.obs_full + env0 * (int64_t)(p.W * p.H * 3));
   } else {
+    // DEC: the one door whose state the cell code cannot show (DoorKey's, at (split_idx, door_idx) for the whole
+    // episode) is read back once per step; gone (walked through while open: move_agent overwrites it) or open -> no overlay
+    uint32_t doorw = 0xFFFFFFFFu;
+    if (DEC && p.kind == MG_KIND_DOORKEY) {
+      const int dx = spawn_w, dy = (int)(((dk_bits >> 21) & 7u) | ((dk_bits >> 30) << 3));
+      const uint32_t kd = g_get(g, g_off(p, dx, dy)), T = code_T(kd);
+      if ((kd & 1u) && (T == 0u || T == (uint32_t)MG_T_DOOR))
+        doorw = (uint32_t)dx | ((uint32_t)dy << 6) | ((T == 0u ? 2u : 1u) << 12) | (code_C(kd) << 16);
+    }
 #pragma unroll
     for (int a = 0; a < A; ++a) {
       uint32_t s[NW + 1];
@@ -693,15 +764,16 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       for (int i = 0; i <= NW; ++i) s[i] = pd_get(pd, a) + (uint32_t)i;
       vm = ~0ull;
 #else
-      dyn_view<V>(p, g, lut, pd_get(pd, a), (uint32_t)(carry >> (8 * a)) & 255u, s, vm);
+      dyn_view<V, DEC>(p, g, lut, pd_get(pd, a), (uint32_t)(carry >> (8 * a)) & 255u, s, vm);
 #endif
-      emit_obs<A, V>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB, ((p.nt_obs >> a) & 1) != 0);
+      emit_obs<A, V, DEC>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB, ((p.nt_obs >> a) & 1) != 0,
+                          nullptr, doorw);
     }
   }
 #endif
 }
 
-template <int A, int V, bool FULL, int PRE>
+template <int A, int V, bool FULL, int PRE, bool DEC>
 __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up to 8 waves per workgroup (dyn_geometry)
   constexpr int ROWB = ViewGeom<V>::ROWB;
   extern __shared__ __align__(16) uint8_t smem[];
@@ -754,7 +826,7 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up t
     const int64_t cn = c + cstride;
     const bool more = cn < p.n_chunks;          // wave-uniform
     if (more) dyn_load<A, PRE>(p, cn * kWave, lane, nxt);
-    dyn_chunk<A, V, FULL, PRE>(p, dist, lut, base, pidx, cpc, stage, gw, lane, c * kWave, cur, err);
+    dyn_chunk<A, V, FULL, PRE, DEC>(p, dist, lut, base, pidx, cpc, stage, gw, lane, c * kWave, cur, err);
     if (more) {
       if (FULL) dyn_wait<A, kFull, PRE>(nxt); else dyn_wait<A, kLo, PRE>(nxt);
       cur = nxt;
@@ -763,12 +835,12 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up t
   if (err) atomicOr(p.err, err);
 }
 
-// mg_export_grid: de-block the per-env grids into plain [n][W*H] byte arrays
+// mg_export_grid: de-block the per-env grids into plain [n][W*H] byte arrays of public kind ids
 __global__ void export_grid_kernel(const uint8_t* grid, int GW, int cells, int64_t n_envs, uint8_t* out) {
   const int64_t total = n_envs * cells;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = i / cells;
     const int ci = (int)(i - n * cells);
-    out[i] = grid[((n >> 6) * GW * 4 + ci) * kWave + (n & 63)];
+    out[i] = (uint8_t)kind_from_code(grid[((n >> 6) * GW * 4 + ci) * kWave + (n & 63)]);
   }
 }

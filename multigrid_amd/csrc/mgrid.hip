@@ -226,7 +226,9 @@ __device__ __forceinline__ uint32_t view_row_bit(uint32_t row, uint32_t cell_wor
 // process_vis + own cell + encode: from the V*V cell words (w[vx*V+vy]: type | color<<8 | state<<16 in the low three
 // bytes, the top byte is ignored) and the per-row opacity bits (opq[vy] bit vx) to the dword stream
 // and the visibility mask vm (bit vy*V + vx).  Four 3-byte codes make three dwords, one v_perm_b32 each.
-template <int V>
+// DEC (mutable-grid kernels, mg_dyn.h): the cell words are raw products of cell codes instead — after the mask
+// (state = 0, type, 0, colour) from byte 0 up — so the visibility mask also strips them and the selectors differ.
+template <int V, bool DEC = false>
 __device__ __forceinline__ void pack_view(uint32_t (&w)[V * V], const uint32_t (&opq)[V], bool see_through,
                                           uint32_t own_code, uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t& vm) {
   constexpr int NW = ViewGeom<V>::NW, NC = V * V;
@@ -245,16 +247,20 @@ __device__ __forceinline__ void pack_view(uint32_t (&w)[V * V], const uint32_t (
 #pragma unroll
   for (int c = 0; c < NC; ++c) {                                 // unseen -> (0,0,0)
     const int vx = c / V, vy = c % V;
-    w[c] &= (uint32_t)__builtin_amdgcn_sbfe((int)vis[vy], vx, 1);
+    w[c] &= (uint32_t)__builtin_amdgcn_sbfe((int)vis[vy], vx, 1) & (DEC ? 0x07000F00u : 0xFFFFFFFFu);
   }
+  // (type, colour, state) of a cell word are its bytes (0, 1, 2), or (1, 3, 0) with DEC
+  constexpr uint32_t kSel0 = DEC ? 0x05000301u : 0x04020100u;    // c0.t c0.c c0.s c1.t
+  constexpr uint32_t kSel1 = DEC ? 0x07050003u : 0x05040201u;    // c1.c c1.s c2.t c2.c
+  constexpr uint32_t kSel2 = DEC ? 0x04070500u : 0x06050402u;    // c2.s c3.t c3.c c3.s
 #pragma unroll
   for (int q = 0; q < NC / 4; ++q) {
     const uint32_t c0 = w[4 * q], c1 = w[4 * q + 1], c2 = w[4 * q + 2], c3 = w[4 * q + 3];
-    s[3 * q] = __builtin_amdgcn_perm(c1, c0, 0x04020100u);       // c0.0 c0.1 c0.2 c1.0
-    s[3 * q + 1] = __builtin_amdgcn_perm(c2, c1, 0x05040201u);   // c1.1 c1.2 c2.0 c2.1
-    s[3 * q + 2] = __builtin_amdgcn_perm(c3, c2, 0x06050402u);   // c2.2 c3.0 c3.1 c3.2
+    s[3 * q] = __builtin_amdgcn_perm(c1, c0, kSel0);
+    s[3 * q + 1] = __builtin_amdgcn_perm(c2, c1, kSel1);
+    s[3 * q + 2] = __builtin_amdgcn_perm(c3, c2, kSel2);
   }
-  s[NW - 1] = w[NC - 1] & 0xFFFFFFu;
+  s[NW - 1] = DEC ? __builtin_amdgcn_perm(0u, w[NC - 1], 0x0C000301u) : (w[NC - 1] & 0xFFFFFFu);
   s[NW] = 0;
 }
 
@@ -314,9 +320,12 @@ __device__ __forceinline__ void store_vec16(uint4* dst, const uint4 v, bool nt) 
 }
 
 // Stage the 64 images of this wave in LDS and stream them to HBM as one contiguous chunk.
-template <int A, int V>
+// DOOR (mutable-grid kernels that decode cell codes arithmetically, mg_dyn.h): doorw = x | y<<6 | state<<12 | colour<<16
+// of the one closed or locked door the view cannot decode from its cell code (0xFFFFFFFF: none), patched in like an agent.
+template <int A, int V, bool DOOR = false>
 __device__ __forceinline__ void emit_obs(pd_t<A> pd, int a, uint32_t (&s)[ViewGeom<V>::NW + 1], uint64_t vm,
-                                         uint32_t* stage, int lane, uint8_t* gchunk, bool nt, uint8_t* gchunk2 = nullptr) {
+                                         uint32_t* stage, int lane, uint8_t* gchunk, bool nt, uint8_t* gchunk2 = nullptr,
+                                         uint32_t doorw = 0xFFFFFFFFu) {
   constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
   const uint32_t me = pd_get(pd, a);
   const int x = aw_x(me), y = aw_y(me), d = aw_d(me);
@@ -353,6 +362,19 @@ __device__ __forceinline__ void emit_obs(pd_t<A> pd, int a, uint32_t (&s)[ViewGe
         q[0] = (uint8_t)MG_T_AGENT;
         q[1] = (uint8_t)b;
         q[2] = (uint8_t)(((uint32_t)aw_d(o) - (uint32_t)d - 1u) & 3u);
+      }
+    }
+  }
+  if (DOOR && doorw != 0xFFFFFFFFu) {        // Door.encode of a door that is not open: (4, colour, 1 closed | 2 locked)
+    const int ox = aw_x(doorw) - x, oy = aw_y(doorw) - y;
+    const int along = ox * fx + oy * fy, side = ox * rx + oy * ry;
+    const int vy = V - 1 - along, vx = side + V / 2;
+    if ((unsigned)vx < (unsigned)V && (unsigned)vy < (unsigned)V) {
+      if ((vm >> (vy * V + vx)) & 1u) {
+        uint8_t* q = sb + (vx * V + vy) * 3;
+        q[0] = (uint8_t)MG_T_DOOR;
+        q[1] = (uint8_t)((doorw >> 16) & 7u);
+        q[2] = (uint8_t)((doorw >> 12) & 3u);
       }
     }
   }
@@ -1031,7 +1053,7 @@ __global__ void sqrt_probe(int n, double* out) {
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= n; k += gridDim.x * blockDim.x) out[k] = __dsqrt_rn((double)k);
 }
 
-// mg_set_maps: the caller's per-env layouts (device uint8[n_envs][H*W*3] cell triples) -> kind ids in the blocked layout of
+// mg_set_maps: the caller's per-env layouts (device uint8[n_envs][H*W*3] cell triples) -> cell codes in the blocked layout of
 // the per-env grids, plus every env's own shaper goal (get_goal_position, v8_robust_ppo.py:159-169: first goal scanning
 // x-major, (13,13) if none) into aux word 0.  One thread per env: a one-off import, not a hot path.
 __global__ void import_maps_kernel(const uint8_t* cells, int W, int H, int GW, int A, int64_t n_envs, uint8_t* grid0, uint32_t* aux,
@@ -1045,11 +1067,12 @@ __global__ void import_maps_kernel(const uint8_t* cells, int W, int H, int GW, i
   bool bad = false;
   for (int ci = 0; ci < ncell; ++ci) {
     const uint32_t t = c[ci * 3], col = c[ci * 3 + 1] & 7u, st = c[ci * 3 + 2];
-    uint32_t k = 0;
+    uint32_t k = K_NONE;
     switch (t) {
       case MG_T_UNSEEN: case MG_T_EMPTY: ++n_free; break;
-      case MG_T_WALL: case MG_T_GOAL: case MG_T_LAVA: case MG_T_FLOOR: case MG_T_KEY: case MG_T_BALL: case MG_T_BOX: k = t * 8 + col; break;
-      case MG_T_DOOR: if (st > 2) { bad = true; k = K_WALL; } else k = 128 + col * 4 + st; break;
+      case MG_T_WALL: case MG_T_GOAL: case MG_T_LAVA: case MG_T_FLOOR: case MG_T_KEY: case MG_T_BALL: case MG_T_BOX:
+        k = code_from_kind(t * 8 + col); break;
+      case MG_T_DOOR: if (st > 2) { bad = true; k = K_WALL; } else k = code_from_kind(128 + col * 4 + st); break;
       default: bad = true; k = K_WALL; break;
     }
     g[(int64_t)ci * kWave] = (uint8_t)k;
@@ -1089,21 +1112,32 @@ struct Variant { int A, V; kernel_fn generic[2], table[2]; int entw; kernel_fn r
                               {mg_rollout_kernel<A, V, false>, mg_rollout_kernel<A, V, true>}}
 #define MG_VARIANT_GEN(A, V) {A, V, {mg_kernel<A, V, false, false>, mg_kernel<A, V, false, true>}, {nullptr, nullptr}, 0, \
                               {mg_rollout_kernel<A, V, false>, nullptr}}
+// MG_MIN_BUILD (tools/gpu.sh build ... -DMG_MIN_BUILD): only what tools/kbench times — quick A/B builds, never the product
 const Variant kVariants[] = {
+#ifdef MG_MIN_BUILD
+    MG_VARIANT_TAB(3, 5),
+#else
     MG_VARIANT_TAB(1, 5), MG_VARIANT_TAB(2, 5), MG_VARIANT_TAB(3, 5), MG_VARIANT_TAB(4, 5), MG_VARIANT_TAB(5, 5), MG_VARIANT_TAB(3, 3),
     MG_VARIANT_GEN(1, 7), MG_VARIANT_GEN(2, 7), MG_VARIANT_GEN(3, 7),
+#endif
 };
 
 // mutable-grid kernel instantiations
-struct DynVariant { int A, V; bool full; int pre; kernel_fn fn; };
-#define MG_DYN(A, V, FULL, PRE) {A, FULL ? 0 : V, FULL, PRE, mg_dyn_kernel<A, V, FULL, PRE>}
+// fn[0] decodes a view cell through the LDS table, fn[1] arithmetically (DEC, mg_dyn.h); the fully observed kinds have no views
+struct DynVariant { int A, V; bool full; int pre; kernel_fn fn[2]; };
+#define MG_DYN(A, V, FULL, PRE) {A, FULL ? 0 : V, FULL, PRE, {mg_dyn_kernel<A, V, FULL, PRE, false>, \
+                                 FULL ? (kernel_fn) nullptr : (kernel_fn)mg_dyn_kernel<A, V, FULL, PRE, !FULL>}}
 const DynVariant kDynVariants[] = {
+#ifdef MG_MIN_BUILD
+    MG_DYN(3, 7, false, 16), MG_DYN(2, 7, false, 16), MG_DYN(3, 5, false, 64), MG_DYN(3, 5, true, 16), MG_DYN(3, 5, true, 64),
+#else
     MG_DYN(1, 7, false, 16), MG_DYN(2, 7, false, 16), MG_DYN(3, 7, false, 16), MG_DYN(4, 7, false, 16), MG_DYN(5, 7, false, 16),
     MG_DYN(1, 5, false, 16), MG_DYN(2, 5, false, 16), MG_DYN(3, 5, false, 16), MG_DYN(4, 5, false, 16),
     MG_DYN(1, 5, false, 64), MG_DYN(2, 5, false, 64), MG_DYN(3, 5, false, 64),
     // fully observed kinds (no views; the V parameter is unused)
     MG_DYN(1, 5, true, 16), MG_DYN(2, 5, true, 16), MG_DYN(3, 5, true, 16), MG_DYN(4, 5, true, 16),
     MG_DYN(1, 5, true, 64), MG_DYN(2, 5, true, 64), MG_DYN(3, 5, true, 64),
+#endif
 };
 
 // Host twin of static_view<V>: the static view of (x, y, dir) as a table entry
@@ -1242,7 +1276,8 @@ struct mg_handle {
   uint32_t* aux;
   uint8_t* obs_full;
   bool full_obs;
-  int dyn_waves_cu;      // waves of the mutable-grid kernel a CU can hold by registers
+  int dyn_waves_cu2[2];  // waves of the mutable-grid kernel (table-decoding / arithmetic) a CU can hold by registers
+  bool dyn_dec;          // this layout family's views decode their cell codes arithmetically (DEC, mg_dyn.h)
   int fixed_mode; uint64_t fixed_pd; uint32_t fixed_pd_hi;       // mg_set_fixed_spawn
   std::vector<uint8_t> free_cells;         // host copy: cell (y*W + x) holds nothing (placement checks)
   int LW, LH;            // dims of the mutable-grid kernel's relative distance LUT
@@ -1338,6 +1373,15 @@ void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid
   *lds_out = lds;
 }
 
+// Which instantiation of the mutable-grid kernel a launch runs: the arithmetic decode (DEC) when the layout family
+// allows it — no doors, or DoorKey's one tracked door — and the kernel exists (the fully observed kinds have no views).
+// MG_DEBUG_DEC=0 forces the table decode (tests: both instantiations on the same layouts).
+int dyn_dec_index(const mg_handle* h) {
+  if (!h->dvar || !h->dvar->fn[1] || !h->dyn_dec) return 0;
+  if (const char* e = debug_env("MG_DEBUG_DEC")) return atoi(e) ? 1 : 0;
+  return 1;
+}
+
 // Mutable-grid launch geometry: 4 waves per workgroup (fewer for small batches), as many workgroups
 // per CU as LDS allows; persistent over chunks.
 void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* lds_out) {
@@ -1349,7 +1393,7 @@ void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* l
   // (queried from the code object at mg_create: 512 VGPRs per SIMD lane / the kernel's count, x 4 SIMDs), and
   // whatever fits 160 KB of LDS.  Ties go to the smaller workgroup; small batches shrink it further so that
   // every CU gets work.
-  const int kDynWavesPerCU = h->dyn_waves_cu;
+  const int kDynWavesPerCU = h->dyn_waves_cu2[dyn_dec_index(h)];
   int nw = 1, best = 0;
   for (int cand = 1; cand <= 8; ++cand) {
     const size_t need = fixed + cand * per_wave;
@@ -1428,7 +1472,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
   if (h->dynamic) {
     dyn_geometry(h, &nw, &grid, &lds);
-    hipLaunchKernelGGL(h->dvar->fn, dim3(grid), dim3(nw * kWave), lds, h->stream, p);
+    hipLaunchKernelGGL(h->dvar->fn[dyn_dec_index(h)], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
     HIP_TRY(hipGetLastError());
     if (op == OP_RESET) h->reset_epoch += 1;
     return launch_ep_stats(h, op, mask, 0, nullptr);
@@ -1485,8 +1529,8 @@ int enable_dynamic(mg_handle* h, const std::vector<uint8_t>& kinds, int gx, int 
     if (rc == MG_OK) rc = dalloc(h, &h->grid, (size_t)h->n_chunks * h->GW * kWave);
     if (rc != MG_OK) return rc;
   }
-  std::vector<uint32_t> base((size_t)h->GW, 0u);
-  for (size_t i = 0; i < kinds.size(); ++i) base[i >> 2] |= (uint32_t)kinds[i] << (8 * (i & 3));
+  std::vector<uint32_t> base((size_t)h->GW, 0u);       // the layout as cell codes (mg_dyn.h), from public kind ids
+  for (size_t i = 0; i < kinds.size(); ++i) base[i >> 2] |= code_from_kind(kinds[i]) << (8 * (i & 3));
   // relative distance LUT: d[|dy|*LW + |dx|] = np.linalg.norm((dx, dy)) (v8:192).  (gx, gy) can lie outside a
   // small grid (the (13,13) fallback of get_goal_position, v8:167), so the table covers max(W, gx+1) x max(H, gy+1).
   const int LW = std::max(c.width, gx + 1), LH = std::max(c.height, gy + 1);
@@ -1576,14 +1620,17 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   h->base_grid = nullptr; h->grid0 = nullptr; h->per_env_maps = false; h->carry = nullptr; h->grid = nullptr; h->aux = nullptr; h->obs_full = nullptr;
   h->full_obs = c.env_kind == MG_KIND_MEETUP; h->LW = c.width; h->LH = c.height;
   h->ep_on = false; h->ep_thr = 0.0; memset(&h->ep, 0, sizeof(h->ep));
-  h->dyn_waves_cu = 8; h->fixed_mode = 0; h->fixed_pd = 0; h->fixed_pd_hi = 0;
-  if (dvar) {
+  h->dyn_waves_cu2[0] = h->dyn_waves_cu2[1] = 8; h->dyn_dec = false; h->fixed_mode = 0; h->fixed_pd = 0; h->fixed_pd_hi = 0;
+  for (int v = 0; dvar && v < 2; ++v) {
     hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(dvar->fn)) == hipSuccess && fa.numRegs > 0) {
+    if (dvar->fn[v] && hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(dvar->fn[v])) == hipSuccess && fa.numRegs > 0) {
       const int regs = (fa.numRegs + 7) / 8 * 8;                  // gfx950: 512 VGPRs per SIMD lane, allocated in 8s
-      h->dyn_waves_cu = 4 * std::max(1, std::min(8, 512 / regs));
+      h->dyn_waves_cu2[v] = 4 * std::max(1, std::min(8, 512 / regs));
     }
   }
+  // DoorKey's door row rides in five bits of the state word (mg_dyn.h): grids up to 33 rows; Cluttered / FourRooms
+  // layouts never hold a door; a static layout decides in mg_set_static_map
+  h->dyn_dec = (c.env_kind == MG_KIND_DOORKEY && c.height <= 33) || c.env_kind == MG_KIND_CLUTTERED || c.env_kind == MG_KIND_FOURROOMS;
   h->use_table = false; h->n_entries = 0; h->view_table = nullptr; h->cell_index = nullptr;
   h->stride = (c.n_envs + 63) / 64 * 64;
   h->n_chunks = h->stride / 64;
@@ -1600,7 +1647,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (e != hipSuccess) { delete h; return fail(MG_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
   for (kernel_fn fn : {var ? var->generic[0] : nullptr, var ? var->generic[1] : nullptr, var ? var->table[0] : nullptr,
                        var ? var->table[1] : nullptr, var ? var->roll[0] : nullptr, var ? var->roll[1] : nullptr,
-                       dvar ? dvar->fn : nullptr}) {
+                       dvar ? dvar->fn[0] : nullptr, dvar ? dvar->fn[1] : nullptr}) {
     if (!fn) continue;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
     if (e != hipSuccess) { (void)hipStreamDestroy(h->stream); delete h; return fail(MG_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
@@ -1640,9 +1687,9 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
     std::vector<uint8_t> kinds((size_t)c.width * c.height, 0);
     for (int y = 0; y < c.height; ++y)
       for (int x = 0; x < c.width; ++x)
-        if (x == 0 || y == 0 || x == c.width - 1 || y == c.height - 1) kinds[(size_t)y * c.width + x] = (uint8_t)K_WALL;
+        if (x == 0 || y == 0 || x == c.width - 1 || y == c.height - 1) kinds[(size_t)y * c.width + x] = (uint8_t)MG_KIND_ID(MG_T_WALL, 5, 0);
     const bool fixed_goal = c.env_kind == MG_KIND_DOORKEY || (c.env_kind == MG_KIND_CLUTTERED && c.gen_n_goals == 0);
-    if (fixed_goal) kinds[(size_t)(c.height - 2) * c.width + (c.width - 2)] = (uint8_t)K_GOAL;
+    if (fixed_goal) kinds[(size_t)(c.height - 2) * c.width + (c.width - 2)] = (uint8_t)MG_KIND_ID(MG_T_GOAL, 1, 0);
     // shaper goal (v8:159-169): that cell; Meetup has no goal cell -> the (13,13) fallback; a scattered Cluttered
     // goal is per env (mg_buffers.aux word 0) and overrides this in the kernel
     const bool no_goal = c.env_kind == MG_KIND_MEETUP;
@@ -1670,7 +1717,7 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
   const int W = cfg.width, H = cfg.height, V = cfg.view_size, pad = V - 1;
   {
     // any object an agent can pick up, toggle or walk onto and destroy -> per-env mutable grids
-    bool objects = false;
+    bool objects = false, doors = false;
     std::vector<uint8_t> kinds((size_t)W * H, 0);
     h->free_cells.assign((size_t)W * H, 0);
     for (int i = 0; i < W * H; ++i) h->free_cells[i] = cells[(size_t)i * 3] <= MG_T_EMPTY;
@@ -1686,7 +1733,7 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
           kinds[i] = (uint8_t)(c[0] * 8 + (c[1] & 7)); objects = true; break;
         case MG_T_DOOR:
           if (c[2] > 2) return fail(MG_EINVAL, "door state must be 0 (open), 1 (closed) or 2 (locked)");
-          kinds[i] = (uint8_t)(128 + (c[1] & 7) * 4 + c[2]); objects = true; break;
+          kinds[i] = (uint8_t)(128 + (c[1] & 7) * 4 + c[2]); objects = doors = true; break;
         default: return fail(MG_EUNSUPPORTED, "unknown object type in the map");
       }
     }
@@ -1696,6 +1743,7 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
         for (int j = 0; j < H; ++j)
           if (cells[((size_t)j * W + i) * 3] == MG_T_GOAL) { gx = i; gy = j; break; }
       if (gx < 0) { gx = 13; gy = 13; }
+      h->dyn_dec = !doors;     // a door's closed / locked state is not in its cell code: such layouts decode through the table
       return enable_dynamic(h, kinds, gx, gy);
     }
     h->dynamic = false;
@@ -1782,6 +1830,7 @@ int mg_set_maps(mg_handle* h, const uint8_t* cells) {
   if (c.env_kind != MG_KIND_STATIC) return fail(MG_EINVAL, "this env_kind generates its own grids; no caller-supplied maps");
   // every env gets its own (mutable) grid; the reset template is per env, the shared template is the bare border
   std::vector<uint8_t> kinds((size_t)c.width * c.height, 0);
+  h->dyn_dec = false;                             // the layouts are on the device and may hold doors: table decode
   int rc = enable_dynamic(h, kinds, 13, 13);      // distance table large enough for the (13,13) fallback goal
   if (rc != MG_OK) return rc;
   DeviceGuard g(h->device);
@@ -2187,6 +2236,18 @@ int mg_debug_device_rewards(int device, int32_t max_steps, double* out) {
   hipError_t e = hipMemcpy(out, d, ((size_t)max_steps + 1) * 8, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) return fail(MG_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+  return MG_OK;
+}
+
+// Test hook (host only, no GPU): the mutable grids' cell code of a public kind id (MG_KIND_ID), the id it exports back
+// as, its table word (encode() triple | flags<<24) and the triple the arithmetic decode of the views extracts from the code
+// (type | colour<<8; state is always 0 there: a closed or locked door is shown through the overlay instead).
+int mg_debug_cell_code(int32_t kind, uint32_t* code, uint32_t* kind_back, uint32_t* table_word, uint32_t* decoded) {
+  if (kind < 0 || kind > 255 || !code || !kind_back || !table_word || !decoded) return fail(MG_EINVAL, "bad argument");
+  const uint32_t k = code_from_kind((uint32_t)kind);
+  *code = k; *kind_back = kind_from_code(k); *table_word = kind_word(k);
+  const uint32_t w = (k * kDecMul) & kDecMask;
+  *decoded = ((w >> 8) & 255u) | ((w >> 24) << 8);
   return MG_OK;
 }
 

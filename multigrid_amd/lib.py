@@ -94,6 +94,7 @@ SYMBOLS = {
     'mg_debug_device_sqrt': (C.c_int, [C.c_int, C.c_int32, C.c_void_p]),
     'mg_debug_device_rewards': (C.c_int, [C.c_int, C.c_int32, C.c_void_p]),
     'mg_debug_vis_masks': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    'mg_debug_cell_code': (C.c_int, [C.c_int32] + [C.POINTER(C.c_uint32)] * 4),
     'mg_last_error': (C.c_char_p, []),
     'mg_version': (C.c_char_p, []),
 }

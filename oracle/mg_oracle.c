@@ -116,6 +116,7 @@ typedef struct mgo_env {
   /* procedurally generated kinds (DoorKey): */
   int kind;                    /* KIND_* */
   int spawn_w;                 /* agents are (re)placed at x < spawn_w (doorkey.py:69-86); W otherwise */
+  int door_y;                  /* DoorKey: door_idx of the last _gen_grid (doorkey.py:58-61), mirrored in the state word */
   const int8_t* inj_gen;       /* injected (split_idx, door_idx, key_x, key_y) or NULL */
   const int8_t* inj_obj;       /* injected (x, y, 0, 0) per agent for a carried object re-placed on death, or NULL */
   int8_t last_gen[4], last_objdrop[MAXA * 4];
@@ -142,7 +143,7 @@ mgo_env* mgo_create(int W, int H, int A, int V, int max_steps, int see_through, 
   e->competitive = (A == 1) ? 1 : competitive;      /* multigrid.py:380-381 */
   e->shaping = shaping; e->auto_reset = auto_reset; e->seed = seed; e->gid = gid;
   e->base.w = e->grid.w = W; e->base.h = e->grid.h = H;
-  e->kind = KIND_STATIC; e->spawn_w = W;
+  e->kind = KIND_STATIC; e->spawn_w = W; e->door_y = 0;
   return e;
 }
 void mgo_set_kind(mgo_env* e, int kind) { e->kind = kind; e->full_obs = (kind == KIND_MEETUP); }
@@ -435,6 +436,7 @@ static void gen_doorkey(mgo_env* e) {
   if (split < 1 || split > W - 2 || door < 1 || door > H - 2) { e->err |= ERR_BAD_RESPAWN; split = W <= 5 ? 2 : 3; door = 1; }
   for (int j = 0; j < H; ++j) grid_set(&e->grid, split, j, wall);    /* vert_wall(split_idx, 0) :52 */
   e->spawn_w = split;
+  e->door_y = door;
   for (int a = 0; a < e->A; ++a) place_one_agent(e, a);  /* place_agent(size=(split_idx,height)) :56 */
   const obj_t doorobj = {T_DOOR, C_YELLOW, 2, 0}, keyobj = {T_KEY, C_YELLOW, 0, 0};
   grid_set(&e->grid, split, door, doorobj);              /* put_obj(Door('yellow', is_locked=True)) :60-61 */
@@ -885,7 +887,10 @@ uint32_t mgo_step_state(const mgo_env* e) {
   uint32_t d = 0;
   for (int a = 0; a < e->A; ++a) d |= (uint32_t)(e->done[a] != 0) << a;
   uint32_t w = (uint32_t)e->step_count | (d << 16);
-  if (e->kind == KIND_DOORKEY) w |= (uint32_t)e->spawn_w << 24;  /* DoorKey keeps the spawn region (split_idx) here */
+  /* DoorKey keeps the spawn region (split_idx) in bits 24..29 and the low five bits of the door's row (door_idx) in
+   * bits 21..23 and 30..31 (include/mgrid.h) */
+  if (e->kind == KIND_DOORKEY)
+    w |= ((uint32_t)e->spawn_w << 24) | (((uint32_t)e->door_y & 7u) << 21) | ((((uint32_t)e->door_y >> 3) & 3u) << 30);
   return w;
 }
 /* One-byte cell kind used by the product's per-env grids: 0 = None, door = 128 + color*4 + state,

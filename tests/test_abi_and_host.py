@@ -105,3 +105,34 @@ def test_layout_generators():
   assert int((lava[:, :, 0] == 9).sum()) == 5 and tuple(lava[7, 7]) == (8, 1, 0)
   e = layouts.empty_bordered(6, 4)
   assert e.shape == (4, 6, 3) and int((e[:, :, 0] == 2).sum()) == 2 * 6 + 2 * 2
+
+
+def test_cell_codes_round_trip_and_decode_without_gpu():
+  """The mutable grids' one-byte cell codes (csrc/mg_dyn.h): every public kind id (MG_KIND_ID) survives the round trip
+  through its code; the table word is Door / WorldObj.encode of the object with the reference's behaviour (SURVEY App. A.2);
+  and the views' arithmetic decode of the code gives the same (type, colour) as the table for every kind — state 0, which is
+  wrong only for closed and locked doors: those are what the kernels show through the overlay instead (DoorKey) or keep on
+  the table path (layouts with doors)."""
+  L = lib.load()
+  F_FREE, F_KILL, F_GOAL, F_OVERLAP, F_PICKUP, F_DOOR, F_BOX, F_OPAQUE = 1 << 25, 1 << 26, 1 << 27, 1 << 28, 1 << 29, 1 << 30, 1 << 24, 1 << 31
+  kinds = [(0, (1, 0, 0), F_FREE)]
+  for color in range(6):
+    kinds += [(lib.kind_id(2, color), (2, color, 0), F_OPAQUE), (lib.kind_id(3, color), (3, color, 0), F_OVERLAP),
+              (lib.kind_id(5, color), (5, color, 0), F_PICKUP), (lib.kind_id(6, color), (6, color, 0), F_PICKUP),
+              (lib.kind_id(7, color), (7, color, 0), F_PICKUP | F_BOX), (lib.kind_id(8, color), (8, color, 0), F_KILL | F_GOAL),
+              (lib.kind_id(4, color, 0), (4, color, 0), F_DOOR | F_OVERLAP), (lib.kind_id(4, color, 1), (4, color, 1), F_DOOR | F_OPAQUE),
+              (lib.kind_id(4, color, 2), (4, color, 2), F_DOOR | F_OPAQUE)]
+    if color != 5:
+      kinds.append((lib.kind_id(9, color), (9, color, 0), F_KILL))
+  kinds.append((lib.kind_id(9, 5), (2, 5, 0), F_KILL))       # LavaWall (lava_walls.py:25-38): deadly, transparent, looks like a grey wall
+  codes = set()
+  for kind, triple, flags in kinds:
+    code, back, word, dec = (C.c_uint32() for _ in range(4))
+    assert L.mg_debug_cell_code(kind, C.byref(code), C.byref(back), C.byref(word), C.byref(dec)) == 0
+    assert back.value == kind and 0 < code.value < 256 and code.value not in codes, kind
+    codes.add(code.value)
+    t, c, s = triple
+    assert word.value & 0xFFFFFF == t | c << 8 | s << 16 and word.value >> 24 << 24 == flags, (kind, hex(word.value))
+    assert (code.value & 1) == (1 if flags & F_OPAQUE else 0)          # bit 0 of a code is its opacity
+    if not (t == 4 and s):
+      assert dec.value == t | c << 8, (kind, hex(dec.value))

@@ -211,6 +211,55 @@ def test_object_playground_parity(playground_cells, A, V, n, seed):
   env.close()
 
 
+@pytest.mark.parametrize('size,A,n,steps,max_steps', [(8, 3, 2000, 200, 90), (6, 2, 700, 150, 60)])
+def test_doorkey_table_decode_parity(monkeypatch, size, A, n, steps, max_steps):
+  """DoorKey normally runs the instantiation that decodes cell codes arithmetically and shows the closed / locked door through
+  the overlay; MG_DEBUG_DEC=0 runs the table-decoding instantiation on the same layouts (what layouts with untracked doors
+  get).  Both against the oracle, and against each other."""
+  _need_gpu()
+  env, orc = _doorkey(size, A, n, max_steps, seed=size * 7 + A)
+  monkeypatch.setenv('MG_DEBUG_DEC', '0')
+  tab, _ = _doorkey(size, A, n, max_steps, seed=size * 7 + A)
+  for e in (env, tab):
+    e.reset()
+  orc.reset()
+  for t in range(steps):
+    tab.step_random()
+    monkeypatch.delenv('MG_DEBUG_DEC')
+    env.step_random()
+    monkeypatch.setenv('MG_DEBUG_DEC', '0')
+    orc.step()
+    _cmp(env, orc, 'arithmetic decode, step %d' % t)
+    _cmp(tab, orc, 'table decode, step %d' % t)
+  assert env.check_errors() == 0 and tab.check_errors() == 0 and orc.errors() == 0
+  env.close()
+  tab.close()
+
+
+@pytest.mark.parametrize('A,V,n,seed', [(3, 5, 2000, 14), (2, 7, 800, 18)])
+def test_object_map_without_doors_parity(playground_cells, A, V, n, seed):
+  """The playground without its doors: a fixed layout with keys, balls, boxes, floor, lava — nothing whose state a cell code
+  cannot hold — runs the arithmetic decode (no overlay); with MG_DEBUG_DEC=0 the table decode.  Same bytes as the oracle."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  cells = playground_cells.copy()
+  cells[cells[:, :, 0] == 4] = (1, 0, 0)
+  cells[3, 3] = (9, 5, 0)          # a LavaWall: encodes as a grey wall, transparent, deadly
+  H, W = cells.shape[:2]
+  env = BatchedMultiGrid(cells, n_envs=n, n_agents=A, view_size=V, max_steps=60, shaping='v8', seed=seed, emit_env_reward=True)
+  orc = c_oracle.OracleBatch(cells, n, W=W, H=H, A=A, V=V, max_steps=60, shaping=1, auto_reset=1, seed=seed)
+  assert env.mutable_grid
+  env.reset()
+  orc.reset()
+  _cmp(env, orc, 'reset', step=False)
+  for t in range(160):
+    env.step_random()
+    orc.step()
+    _cmp(env, orc, 'step %d' % t)
+  assert env.check_errors() == 0 and orc.errors() == 0
+  env.close()
+
+
 def test_static_map_switches_back_to_shared_kernel(cluttered_cells):
   """A handle that ran a layout with objects keeps working when given an object-free one again."""
   _need_gpu()
