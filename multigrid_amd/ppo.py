@@ -320,14 +320,45 @@ class EpisodeStats:
     self.ep_return = torch.where(any_fin, cum[-1] - upto, self.ep_return + cum[-1])
     self.ep_touches = torch.where(any_fin, tcum[-1] - tupto, self.ep_touches + tcum[-1])
 
-  def reduce(self):
+  def reduce(self, across_ranks=True):
     """{'episodes', 'mean_collective_return', 'goal_touches'} over every rank's finished episodes."""
     import torch.distributed as dist
     t = self.totals.clone()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-      dist.all_reduce(t)
+    if across_ranks and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+      all_reduce_(t)
     n = float(t[0])
     return {'episodes': int(n), 'mean_collective_return': float(t[1]) / n if n else 0.0, 'goal_touches': int(t[2])}
+
+
+def _through_host(t):
+  """gloo takes device tensors, but on this image its device path stands still for anything beyond a few bytes (round 3:
+  two ranks on one GPU, a 450 KB gradient buffer, both ranks inside all_reduce; the three-double statistics went
+  through).  The rehearsal backend therefore moves device tensors through host memory; RCCL ('nccl') never does."""
+  import torch.distributed as dist
+  return t.is_cuda and dist.get_backend() != 'nccl'
+
+
+def all_reduce_(t):
+  """dist.all_reduce (sum) in place, on whatever backend the process group runs."""
+  import torch.distributed as dist
+  if _through_host(t):
+    h = t.cpu()
+    dist.all_reduce(h)
+    t.copy_(h)
+  else:
+    dist.all_reduce(t)
+  return t
+
+
+def broadcast_(t, src=0):
+  import torch.distributed as dist
+  if _through_host(t):
+    h = t.cpu()
+    dist.broadcast(h, src)
+    t.copy_(h)
+  else:
+    dist.broadcast(t, src)
+  return t
 
 
 class BatchedController:
@@ -338,9 +369,12 @@ class BatchedController:
   policy='simple': the v8 script's SimplePPOAgent per agent (StackedAgentNets); policy='multigrid_net': the
   reference's MultiGridNetwork per agent (networks/multigrid_network.py, BASELINE config 5), fed every agent's
   direction, with a value head added for PPO (MultiGridPPONet).
-  With torch.distributed initialised the policy is wrapped in DistributedDataParallel: the gradients of all A nets go
-  out in one bucketed all-reduce per epoch (RCCL over xGMI on GPUs, gloo in the CPU tests); envs stay sharded and
-  nothing else crosses ranks.  amp=torch.bfloat16 runs the update's forward / backward under autocast — NOT the
+  With torch.distributed initialised (ddp, default: on when there are several ranks) the gradients of all A nets are
+  averaged across ranks in ONE flat-buffer all-reduce per epoch, issued by update() right after backward (RCCL over
+  xGMI on GPUs, gloo in the rehearsals and CPU tests); envs stay sharded and nothing else crosses ranks.  Not
+  DistributedDataParallel: the whole gradient is ~450 KB, so bucketing and overlap with backward have nothing to hide,
+  and its reducer, driving gloo on device buckets from autograd's hooks, is where the two-rank rehearsal on one GPU
+  stood still in round 2 (both ranks inside loss.backward()).  amp=torch.bfloat16 runs the update's forward / backward under autocast — NOT the
   reference's precision (fp32, the default here); it exists to show what the matrix cores would buy.
   """
 
@@ -363,13 +397,13 @@ class BatchedController:
     torch.manual_seed(seed + 1 + (dist.get_rank() if distributed else 0))
     if ddp is None:
       ddp = distributed
-    self.ddp = ddp
-    if ddp:
-      from torch.nn.parallel import DistributedDataParallel as DDP
-      ids = [self.device.index] if self.device.type == 'cuda' else None
-      self.model = DDP(self.policy, device_ids=ids)
-    else:
-      self.model = self.policy
+    self.ddp = bool(ddp)
+    self.model = self.policy
+    if self.ddp:       # every rank starts from rank 0's weights (same seed already gives that; this makes it hold by construction)
+      flat = torch._utils._flatten_dense_tensors([p.data for p in self.policy.parameters()])
+      broadcast_(flat, 0)
+      for p, f in zip(self.policy.parameters(), torch._utils._unflatten_dense_tensors(flat, [p.data for p in self.policy.parameters()])):
+        p.data.copy_(f)
     # one Adam over every agent's parameters = one Adam per agent (the update is elementwise), v8:121
     self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=lr)
     self.stats = EpisodeStats(A, env.n_envs, self.device)
@@ -472,6 +506,16 @@ class BatchedController:
       g_post.replay()
     return buf
 
+  def _allreduce_gradients(self):
+    """Mean of every parameter's gradient over the ranks: one flat buffer, one all-reduce."""
+    import torch.distributed as dist
+    grads = [p.grad for p in self.policy.parameters() if p.grad is not None]
+    flat = torch._utils._flatten_dense_tensors(grads)
+    all_reduce_(flat)
+    flat.div_(dist.get_world_size())
+    for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+      g.copy_(f)
+
   def advantages(self, traj):
     """GAE per agent and env (v8:275-293), then the per-agent normalisation of update_agent (v8:308-317): float32
     tensors [A, T*N] (advantages, returns)."""
@@ -504,7 +548,9 @@ class BatchedController:
         logits, values = self.model(images, dirs)
       per_agent = ppo_loss_terms(logits, values, acts, old_lp, adv, ret)       # [A]
       self.optimizer.zero_grad(set_to_none=True)
-      per_agent.sum().backward()                     # DDP all-reduces the gradients here
+      per_agent.sum().backward()
+      if self.ddp:
+        self._allreduce_gradients()
       self.policy.clip_grad_norm_(max_grad_norm)
       self.optimizer.step()
       losses.append(per_agent.detach())

@@ -326,6 +326,31 @@ def test_gpu_rollout_update_on_device_env():
 
 
 @pytest.mark.gpu
+def test_two_rank_training_on_one_gpu_keeps_the_ranks_in_lockstep(tmp_path):
+  """BASELINE config 5's multi-rank leg, rehearsed the only way one card allows: two ranks of `python -m
+  multigrid_amd.train` under torch.distributed.run, gloo, both on cuda:0 — sharded envs, HIP-graph rollouts, four
+  epochs per iteration with one flat gradient all-reduce each, statistics all-reduced.  Round 2's rehearsal stood still
+  inside loss.backward() (DistributedDataParallel's reducer driving gloo on device buckets); the flat all-reduce does
+  not.  Done = three iterations printed and bit-identical weights on both ranks."""
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  import json
+  import subprocess
+  port = 29800 + (os.getpid() % 150)
+  prefix = os.path.join(str(tmp_path), 'w')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', str(port), '-m', 'multigrid_amd.train', '--backend', 'gloo', '--all-on-device0', '--envs', '512',
+         '--steps', '25', '--iters', '3', '--hang-dump', '60', '--dump-weights', prefix, '--out', os.path.join(str(tmp_path), 'best')]
+  r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=200)
+  assert r.returncode == 0, r.stderr[-3000:]
+  lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+  assert [l['iter'] for l in lines] == [0, 1, 2] and all(np.isfinite(l['loss']).all() for l in lines)
+  w0 = torch.load(prefix + '.rank0.pt', weights_only=True)
+  w1 = torch.load(prefix + '.rank1.pt', weights_only=True)
+  assert sorted(w0) == sorted(w1) and all(torch.equal(w0[k], w1[k]) for k in w0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('policy', ['simple', 'multigrid_net'])
 def test_gpu_gae_and_loss_against_the_reference_loops(policy):
   """On the device, on a real rollout of the HIP env: the scan GAE + per-agent normalisation against the reference's
