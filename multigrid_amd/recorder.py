@@ -346,11 +346,12 @@ class _V7Shaper:
     return self.sh.shape_rewards(env, [env.agent_pos[i] for i in range(env.n_agents)], rewards, actions)
 
 
-def record_reference(reference_path, env_id, episodes, seed=0, shaping='v8', max_len=None):
+def record_reference(reference_path, env_id, episodes, seed=0, shaping='v8', max_len=None, policy=None):
   """Records `episodes` random-policy episodes of the real reference env `env_id`.  Covers the ids whose reset is one of the
   device kinds with random starts (Cluttered family, DoorKey, Meetup, FourRooms / TwoRooms, Empty-Random, WallsAreLava) in
   their multi-agent container shapes; the `*-Minigrid-*` ids (unwrapped image / scalar reward) and EmptyEnv's fixed starts
-  (displacement chains move agents that did not finish) are not handled by this leg yet."""
+  (displacement chains move agents that did not finish) are not handled by this leg yet.
+  policy: None = uniform random actions, else policy(env, rng) -> a callable (env, obs, t) -> actions."""
   if 'Minigrid' in env_id:
     raise SystemExit('recording the *-Minigrid-* container shapes is not implemented; record the multi-agent id of the same class')
   import importlib
@@ -381,8 +382,8 @@ def record_reference(reference_path, env_id, episodes, seed=0, shaping='v8', max
     shaper = _V7Shaper(importlib.import_module('v7_stable_goal_focused_ppo'), base)
   rec = Recorder(base, shaper=shaper, kind=kind)
   rng = np.random.RandomState(seed)
-  policy = lambda e, obs, t: rng.randint(0, 7, size=e.n_agents)
-  eps = [rec.episode(policy, max_len or base.max_steps) for _ in range(episodes)]
+  act = policy(base, rng) if policy is not None else (lambda e, obs, t: rng.randint(0, 7, size=e.n_agents))
+  eps = [rec.episode(act, max_len or base.max_steps) for _ in range(episodes)]
   cells = None
   if kind == 'static':
     base.reset()
@@ -391,7 +392,10 @@ def record_reference(reference_path, env_id, episodes, seed=0, shaping='v8', max
       for x in range(base.width):
         c = base.grid.get(x, y)
         cells[y, x] = (1, 0, 0) if (c is None or c.type == 'agent') else c.encode()
-  meta = dict(kind=kind, width=base.width, height=base.height, n_agents=base.n_agents, view_size=base.agent_view_size,
+  # fully observed kinds never compute a view (multigrid.py:1043-1045): the reference's agent_view_size there (the grid size,
+  # possibly even) means nothing; the fixture carries the unused default instead, which the kernels are instantiated for
+  view = 7 if getattr(base, 'fully_observed', False) else base.agent_view_size
+  meta = dict(kind=kind, width=base.width, height=base.height, n_agents=base.n_agents, view_size=view,
               max_steps=base.max_steps, see_through_walls=bool(base.see_through_walls), competitive=bool(base.competitive),
               shaping=shaping or 'none', source='reference %s via gym.make(%r)' % (reference_path, env_id))
   if kind in ('cluttered', 'meetup'):

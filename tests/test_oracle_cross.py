@@ -89,3 +89,58 @@ def test_c_oracle_vs_python_live_with_lava(empty_cells):
     assert [float(r) for r in prew] == crew and pdone == cdone
     assert [tuple(int(v) for v in p) for p in py.agent_pos] == [tuple(int(v) for v in p) for p in c.agent_pos]
   assert deaths > 0 and c.errors() == 0
+
+
+@pytest.mark.parametrize('name', ['refL0_cluttered_fixed.npz', 'refL0_doorkey_6x6.npz'])
+def test_python_restatement_replays_the_reference_recorded_fixtures(name):
+  """The fixtures recorded from the reference's own env code (tests/golden/make_refL0_fixtures.py; over stand-in gym /
+  gym-minigrid packages, so parity stays unpinned) on the SECOND oracle: the Python restatement is fed the recorded draws in
+  the order the reference consumed them — DoorKey: split_idx, every agent's (x, y, dir), door_idx, the key's (x, y); a step:
+  for each finishing agent in acting order the re-placed object's (x, y), then its respawn (x, y, dir) — and must reproduce
+  every observation, reward, position and carried object.  (tests/test_recorder.py replays the same files on the C oracle.)"""
+  from multigrid_amd import recorder
+  rec = recorder.load(os.path.join(os.path.dirname(GOLD), name))
+  m = rec['meta']
+  E, T, A = rec['actions'].shape
+  queue, order = [], []
+
+  def rand_int(lo, hi):
+    v = queue.pop(0)
+    assert lo <= v < hi, (lo, v, hi)
+    return v
+
+  for e in range(E):
+    spawn = [int(v) for a in range(A) for v in rec['spawn'][e, a, :3]]
+    kw = dict(n_agents=A, view_size=m['view_size'], rand_int=rand_int, order_fn=lambda: order[-1])
+    if m['kind'] == 'doorkey':
+      split, door, kx, ky = (int(v) for v in rec['gen'][e])
+      queue[:] = [split] + spawn + [door, kx, ky]
+      env = py_ref_env.PyDoorKeyEnv(size=m['width'], **kw)
+      env.max_steps = m['max_steps']
+    else:
+      queue[:] = spawn
+      env = py_ref_env.PyRefEnv(rec['cells'], max_steps=m['max_steps'], **kw)
+    assert not queue
+    shaper = py_ref_env.V8Shaper(env)
+    obs = env.gen_obs()
+    assert np.array_equal(np.stack(obs['image']), rec['obs_image'][e, 0]), 'episode %d reset' % e
+    for t in range(int(rec['length'][e])):
+      order.append(rec['order'][e, t])
+      for a in rec['order'][e, t]:
+        if rec['respawn'][e, t, a, 0] >= 0:
+          if rec['objdrop'][e, t, a, 0] >= 0:
+            queue.extend(int(v) for v in rec['objdrop'][e, t, a, :2])
+          queue.extend(int(v) for v in rec['respawn'][e, t, a, :3])
+      acts = [int(v) for v in rec['actions'][e, t]]
+      obs, rew, done, _ = env.step(acts)
+      where = '%s episode %d step %d' % (name, e, t)
+      assert not queue, where
+      assert np.array_equal(np.stack(obs['image']), rec['obs_image'][e, t + 1]), where
+      assert list(obs['direction']) == list(rec['obs_dir'][e, t + 1]), where
+      assert np.array_equal(np.array(rew, np.float64).view(np.int64), rec['env_reward'][e, t].view(np.int64)), where
+      shaped = shaper.shape([env.agent_pos[i] for i in range(A)], rew, acts)
+      assert np.array_equal(np.array(shaped, np.float64).view(np.int64), rec['shaped_reward'][e, t].view(np.int64)), where
+      assert done == bool(rec['done'][e, t]), where
+      assert np.array_equal(np.stack(env.agent_pos), rec['agent_pos'][e, t + 1]), where
+      carry = [recorder._kind_id(c.encode()) if c else 0 for c in env.carrying]
+      assert carry == list(rec['carry'][e, t + 1]), where

@@ -16,6 +16,12 @@ from oracle import c_oracle, py_ref_env
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 FIXTURES = ['replay_cluttered_fixed_15x15.npz', 'replay_doorkey_6x6.npz', 'replay_playground_9x9.npz', 'replay_meetup_8x8.npz',
             'replay_fourrooms_9x9.npz', 'replay_tworooms_6x6.npz']
+# Recorded from the reference's OWN multigrid.py / cluttered.py / doorkey.py / meetup.py / v8 shape_rewards, run in the build
+# container over tests/_shim stand-ins for gym and gym-minigrid (tests/golden/make_refL0_fixtures.py).  They check the layer the
+# reference authored (step / _forward / agent_is_done / gen_obs_grid / rotate_left / Door.toggle / generators / shaper); the
+# minigrid layer under it is this build's restatement in the stand-in too, so parity stays unpinned (meta['caveat'] says so).
+REF_L0_FIXTURES = ['refL0_cluttered_fixed.npz', 'refL0_doorkey_6x6.npz', 'refL0_meetup_8x8.npz']
+FIXTURES = FIXTURES + REF_L0_FIXTURES
 
 
 def replay_on_oracle(rec):
@@ -57,6 +63,16 @@ def test_fixture_replays_on_the_c_oracle(name):
   rec = recorder.load(os.path.join(GOLDEN, name))
   assert rec['meta']['kind'] in ('static', 'doorkey', 'cluttered', 'meetup', 'fourrooms')
   assert replay_on_oracle(rec) == 0
+
+
+@pytest.mark.parametrize('name', REF_L0_FIXTURES)
+def test_reference_recorded_fixtures_say_what_they_are(name):
+  rec = recorder.load(os.path.join(GOLDEN, name))
+  m = rec['meta']
+  assert m['source'].startswith('reference ') and 'unpinned' in m['caveat'] and 'stand-ins' in m['caveat']
+  assert int((rec['env_reward'] > 0).sum()) > 50          # goal touches / meeting progress were recorded, not just idling
+  if m['kind'] == 'doorkey':
+    assert int(((rec['carry'][:, 1:] != 0) & (rec['carry'][:, :-1] == 0)).sum()) > 5 and int((rec['objdrop'][..., 0] >= 0).sum()) > 5
 
 
 def test_record_save_load_round_trip(tmp_path, cluttered_cells):
