@@ -98,6 +98,35 @@ def measured_traffic(envs):
   return None, None
 
 
+def gather_ranks(dist, mine, world):
+  """Every rank's own record ({rank, local_rank, device, pci_bus_id, kernel_ms, ...}) on every rank, in rank order."""
+  if dist is None or world == 1:
+    return [mine]
+  out = [None] * world
+  dist.all_gather_object(out, mine)
+  return sorted(out, key=lambda r: r['rank'])
+
+
+def check_distinct_devices(ranks, allow_shared):
+  """A multi-GPU line must prove that N distinct devices took part: two ranks on one PCI bus id are an error unless the
+  run was started as a one-card rehearsal (--all-on-device0)."""
+  ids = [r.get('pci_bus_id') for r in ranks]
+  dup = sorted({i for i in ids if i is not None and ids.count(i) > 1})
+  if dup and not allow_shared:
+    raise SystemExit('bench.py: ranks share a device (PCI bus id %s): %s' % (', '.join(dup), [(r['rank'], r.get('pci_bus_id')) for r in ranks]))
+  return len({i for i in ids if i is not None})
+
+
+def device_record(torch, rank, local_rank):
+  p = torch.cuda.get_device_properties(local_rank)
+  bus = None
+  if hasattr(p, 'pci_bus_id'):
+    bus = '%04x:%02x:%02x' % (getattr(p, 'pci_domain_id', 0), p.pci_bus_id, getattr(p, 'pci_device_id', 0))
+  return {'rank': rank, 'local_rank': local_rank, 'device': p.name, 'pci_bus_id': bus,
+          'uuid': str(getattr(p, 'uuid', '')) or None, 'compute_units': p.multi_processor_count,
+          'hbm_gib': round(p.total_memory / 2.0**30, 1)}
+
+
 def spawn_ranks(n):
   """`python bench.py --gpus N` without a launcher around it: start N fresh ranks (one per GPU) under
   torch.distributed.run and hand their single JSON line through.  Runs before this process has made any GPU call
@@ -224,7 +253,7 @@ def main():
     wall = time.perf_counter() - t0
     if dist is not None:
       dist.barrier()
-    kernel_ms = ev0.elapsed_time(ev1) / steps      # HIP events on the launch stream
+    kernel_ms = kernel_ms_local = ev0.elapsed_time(ev1) / steps      # HIP events on the launch stream
     wall, value = shard.aggregate(dist, wall, float(n) * A * steps, world)   # max over ranks
     kernel_ms, _ = shard.aggregate(dist, kernel_ms, 0.0, world)
     long_run = None
@@ -251,7 +280,7 @@ def main():
       long_run = {'plain_launch_ms': p_ms, 'all_reset_launch_ms': r_ms, 'kernel_ms_per_step': cyc,
                   'value': float(n) * A * world / (cyc * 1e-3), 'roofline_frac': b_alg * n / (cyc * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   'note': 'median of 3 episode cycles of %d launches, HIP events; kernel time only' % ms}
-    res = {'n': n, 'A': A, 'V': V, 'b_alg': b_alg, 'wall': wall, 'value': value, 'kernel_ms': kernel_ms,
+    res = {'n': n, 'A': A, 'V': V, 'b_alg': b_alg, 'wall': wall, 'value': value, 'kernel_ms': kernel_ms, 'kernel_ms_local': kernel_ms_local,
            'errs': env.check_errors(), 'launch': env.launch_info(), 'mutable': env.mutable_grid, 'cells': env.cells,
            'reset_frac': reset_frac, 'reset_launches': reset_launches, 'long_run': long_run}
     env.close()
@@ -294,13 +323,21 @@ def main():
 
   m = measure(args.envs, args.warmup, args.steps, long_cycle=True)
   also = None
-  if headline and args.also_envs and args.also_envs != args.envs:
-    also = measure(args.also_envs, min(args.warmup, 100), min(args.steps, 500))
+  # second measurement: BASELINE config 3's literal shape.  One GPU: its per-GPU shard at 8 GPUs (131,072 envs); several
+  # GPUs: the 1,048,576 envs strong-scaled over the ranks that are here
+  also_envs = args.also_envs if world == 1 else max(64, (1 << 20) // world)
+  if headline and args.also_envs and also_envs != args.envs:
+    also = measure(also_envs, min(args.warmup, 100), min(args.steps, 500))
 
   roll = None
   if headline and args.rollout_envs:
     roll = measure_rollout(args.rollout_envs, args.rollout_k, max(1, min(args.steps, 640) // args.rollout_k))
 
+  # who took part: every rank's device, gathered on all ranks; ranks that share a card are an error outside a rehearsal
+  mine = device_record(torch, rank, local_rank)
+  mine.update(kernel_ms=m['kernel_ms_local'], device_errors=m['errs'])
+  ranks = gather_ranks(dist, mine, world)
+  distinct = check_distinct_devices(ranks, args.all_on_device0)
   if rank == 0:
     n, A, V = m['n'], m['A'], m['V']
     achieved = m['b_alg'] * n / (m['kernel_ms'] * 1e-3) / 1e9
@@ -324,11 +361,19 @@ def main():
                      'kernel': ('mg_dyn_kernel<%d,%d>' % (A, V)) if m['mutable'] else
                                ('mg_kernel<%d,%d,%s,fast>' % (A, V, m['launch']['path'])),
                      'kernel_ms': m['kernel_ms'], 'launch': m['launch'], 'alg_bytes_per_launch': m['b_alg'] * n},
-        'device_errors': m['errs'],
+        'device_errors': max(r['device_errors'] for r in ranks),
+        # proof of who took part: one record per rank (device, PCI bus id, its own kernel time), the process group's own
+        # word on its size and backend, and the number of distinct devices among the ranks
+        'distributed': {'backend': dist.get_backend() if dist is not None else None,
+                        'world_size': dist.get_world_size() if dist is not None else 1, 'distinct_devices': distinct,
+                        'shared_device_rehearsal': bool(args.all_on_device0)},
+        'ranks': ranks,
     }
     if also is not None:
       a_ach = also['b_alg'] * also['n'] / (also['kernel_ms'] * 1e-3) / 1e9
-      out['also'] = {'workload': "same env, %d envs per GPU (BASELINE config 3's per-GPU shard of 1M envs over 8 GPUs)" % also['n'],
+      what = ("same env, %d envs per GPU (BASELINE config 3's per-GPU shard of 1M envs over 8 GPUs)" % also['n']) if world == 1 else \
+             ("BASELINE config 3 strong-scaled: %d envs in all, %d per GPU over the %d GPUs of this run" % (also['n'] * world, also['n'], world))
+      out['also'] = {'workload': what, 'scaling': 'weak' if world == 1 else 'strong', 'global_envs': also['n'] * world,
                      'value': also['value'], 'unit': 'agent-steps/s', 'kernel_ms': also['kernel_ms'],
                      'roofline_frac': a_ach / HBM_PEAK_GBS, 'launch': also['launch'], 'device_errors': also['errs']}
     if roll is not None:
@@ -365,11 +410,18 @@ def rehearse_cpu(args):
   wall = time.perf_counter() - t0
   if dist is not None:
     dist.barrier()
+  local_ms = wall / args.steps * 1e3
   wall, value = shard.aggregate(dist, wall, float(n) * 3 * args.steps, world)
+  ranks = gather_ranks(dist, {'rank': rank, 'local_rank': int(os.environ.get('LOCAL_RANK', '0')), 'device': 'cpu (rehearsal)',
+                              'pci_bus_id': 'cpu:%d' % rank, 'kernel_ms': local_ms}, world)
+  distinct = check_distinct_devices(ranks, False)
   if rank == 0:
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     print(json.dumps({'rehearsal': True, 'metric': 'launcher rehearsal (sleep), not a measurement', 'value': value,
+                      'distributed': {'backend': dist.get_backend() if dist is not None else None,
+                                      'world_size': dist.get_world_size() if dist is not None else 1, 'distinct_devices': distinct},
+                      'ranks': ranks,
                       'unit': 'agent-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                       'ms_per_step': wall / args.steps * 1e3,
                       'config': {'envs_per_gpu': n, 'global_envs': n * world, 'env_id_base_of_last_rank': (world - 1) * n}}),

@@ -157,8 +157,10 @@ typedef struct mg_config {
   int32_t gen_n_clutter;     /* n_clutter (cluttered.py:16, meetup.py:33) */
   int32_t gen_flags;         /* MG_GEN_* */
   int32_t reward_dtype;      /* MG_REWARD_F64 (0, default: the reference's Python floats) or MG_REWARD_F32: the reward buffers
-                                hold float — the cast v8 applies before its update, torch.FloatTensor(rewards), v8_robust_ppo.py:311 —
-                                12 bytes less to write per env-step with three agents.  Not with emit_env_reward. */
+                                hold float, 12 bytes less to write per env-step with three agents.  A bandwidth option OUTSIDE the
+                                reference's precision: v8 runs compute_gae on the float64 rewards and casts only the resulting
+                                advantages and returns to float32 (v8_robust_ppo.py:304-311), so rounding the rewards first is
+                                not its arithmetic.  Not with emit_env_reward. */
 } mg_config;
 
 typedef struct mg_buffers {
@@ -335,8 +337,9 @@ int mg_step_random(mg_handle* h, uint8_t* actions_out);
  *              (anything else is treated as a wall and reported as MG_ERR_BAD_MAP)
  *   actions    device uint8[env_stride][MG_SLOTS(A)]                       (in)
  *   env_state  device uint32[env_stride][A+1], layout of mg_buffers        (in/out)
- *   obs_image  device uint8[A][env_stride][V*V*3]; reward device double[A][env_stride]; dir_done device
- *              uint8[env_stride][4 or 8]                                  (out), env_stride = n_envs rounded up to 64
+ *   obs_image  device uint8[A][env_stride][V*V*3]; reward device double[A][env_stride] — float[A][env_stride] behind the same
+ *              pointer when cfg->reward_dtype = MG_REWARD_F32; dir_done device uint8[env_stride][4 or 8]
+ *                                                                          (out), env_stride = n_envs rounded up to 64
  *   err_out    device uint32 (may be NULL): the MG_ERR_* bits of this call
  * Limits: width, height <= 64 and view_size in {3, 5, 7} (what the array was laid out for; MG_EINVAL / MG_EUNSUPPORTED
  * beyond), any n_envs.  Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two
@@ -356,7 +359,9 @@ int mg_step_noalloc(const mg_config* cfg, int device, void* hip_stream, uint64_t
  * its own obs_image / reward / dir_done buffers hold the last step.  Handles without env_reward output only (MG_EUNSUPPORTED
  * otherwise); auto-reset and shaping as configured.  Mutable-grid handles (DoorKey, Meetup, drawn layouts, layouts with objects,
  * mg_set_maps) take the same call with the same result but run it as n_steps launches of their step kernel, each writing into its
- * slot — there is no fused kernel for them; fully observed kinds: obs_image is uint8 [n_steps][env_stride][W*H*3] (mg_buffers.obs_full). */
+ * slot — there is no fused kernel for them, and the last step's outputs are written to the handle's own buffers and copied into
+ * the last slot, one extra full-size obs / reward / dir_done copy per call; fully observed kinds: obs_image is uint8
+ * [n_steps][env_stride][W*H*3] (mg_buffers.obs_full). */
 typedef struct mg_rollout_out {
   uint8_t* obs_image;
   double*  reward;
@@ -382,6 +387,14 @@ int mg_sync(mg_handle* h);
 /* Number of steps taken so far (the Philox step index of the next step). */
 int mg_get_step_index(mg_handle* h, uint64_t* out);
 int mg_set_step_index(mg_handle* h, uint64_t t);
+
+/* Number of explicit reset CALLS made so far (mg_reset, mg_reset_inject*; masked or injected, each call counts once for
+ * every env of the handle): an explicit reset draws under the Philox counter word 2^63 | this number in place of the step
+ * index, so that reset(); reset() redraws (the reference reseeds from the clock, cluttered.py:55-63) and never repeats the
+ * draws of an auto-reset inside a step.  Together with the step index it is all of a handle's generator state: a resumed or
+ * re-created handle (checkpoint, shard change) that restores both reproduces the draws of the one it replaces. */
+int mg_get_reset_index(mg_handle* h, uint64_t* out);
+int mg_set_reset_index(mg_handle* h, uint64_t n);
 
 /* Synchronises, returns and clears the device error word (MG_ERR_* bits). */
 int mg_check_errors(mg_handle* h, uint32_t* out);

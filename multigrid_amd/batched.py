@@ -117,13 +117,24 @@ class BatchedMultiGrid:
       self.carry = _alias(b.carry, (S,) if A <= 4 else (S, 2), '<i4', dev)[:n]   # byte a = kind agent a carries
       self.grid_blocked = _alias(b.grid, (S // 64, self.grid_words * 4, 64), '|u1', dev)  # [chunk][cell][lane], include/mgrid.h
 
+  def _order_behind_torch(self):
+    """The library launches on the handle's stream; tensors handed to it were produced on torch's CURRENT stream.  When the
+    two differ (use_torch_stream=False, or a current stream other than the one adopted at construction) the handle's stream is
+    made to wait for torch's, so that a kernel of the library never reads a buffer a torch kernel is still writing."""
+    hs = C.c_void_p()
+    _lib.check(self.L.mg_get_stream(self.h, C.byref(hs)))
+    cur = torch.cuda.current_stream(self.device)
+    if (hs.value or 0) != cur.cuda_stream:
+      torch.cuda.ExternalStream(hs.value or 0, device=self.device).wait_stream(cur)
+
   def set_maps(self, cells):
     """Per-env layouts (mg_set_maps): cells uint8[N, H, W, 3], env n resets to cells[n] from now on; objects allowed.
     The handle runs the mutable-grid kernel afterwards; call reset() next."""
     t = torch.as_tensor(cells, device=self.device).to(torch.uint8).contiguous()
     assert tuple(t.shape) == (self.n_envs, self.height, self.width, 3), tuple(t.shape)
+    self._order_behind_torch()                # the import kernel (handle's stream) reads `t` (torch's stream)
     _lib.check(self.L.mg_set_maps(self.h, C.c_void_p(t.data_ptr())))
-    torch.cuda.current_stream(self.device).synchronize()      # `t` may go away once the import kernel has read it
+    self.sync()                               # mg_sync: `t` may go away once the import kernel — on the HANDLE's stream — has read it
     self.cells = None
     self._bind()
 
@@ -331,6 +342,7 @@ class BatchedMultiGrid:
     if out is None or out['_K'] != K or out['_act'] is not None:
       out = self._trajectory(K, False)
     ro = _lib.MgRolloutOut(out['_obs'].data_ptr(), out['_reward'].data_ptr(), out['_dd'].data_ptr(), None)
+    self._order_behind_torch()                # the ring was (possibly) just written by torch kernels on torch's stream
     _lib.check(self.L.mg_rollout(self.h, K, C.c_void_p(a.data_ptr()), C.byref(ro)))
     out['_ring'] = a            # keep the ring alive until the launch that reads it has been ordered behind later work
     return out
@@ -352,3 +364,14 @@ class BatchedMultiGrid:
   @step_index.setter
   def step_index(self, t):
     _lib.check(self.L.mg_set_step_index(self.h, int(t)))
+
+  @property
+  def reset_index(self):
+    """Explicit reset calls made so far (mg_get_reset_index): with step_index, all of the handle's generator state."""
+    n = C.c_uint64()
+    _lib.check(self.L.mg_get_reset_index(self.h, C.byref(n)))
+    return n.value
+
+  @reset_index.setter
+  def reset_index(self, n):
+    _lib.check(self.L.mg_set_reset_index(self.h, int(n)))

@@ -488,7 +488,9 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 
   const bool is_step = p.op == OP_STEP;
   if (is_step) {
-    if (p.random_actions) actw = draw_actions<A>(p, n, gid, active);
+    U4 blk = U4{0u, 0u, 0u, 0u};                                                // the step's one Philox block (mgrid.hip)
+    if (MG_ABL != 3 && (p.random_actions || (A > 1 && !p.order))) blk = step_block(p, gid, P_ORDER);
+    if (p.random_actions) actw = draw_actions<A>(p, n, gid, active, blk);
     else {
 #pragma unroll
       for (int a = 0; a < A; ++a) actw |= min(((a < 4 ? in.act >> (8 * a) : in.act2 >> (8 * (a - 4)))) & 255u, 7u) << (3 * a);
@@ -496,7 +498,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     uint32_t step = (st & 0xFFFFu) + 1u;                                        // multigrid.py:968
     uint32_t dbits = (st >> 16) & all;
     if (step > 0xFFFFu) step = 0xFFFFu;
-    const uint32_t ordw = agent_order<A, false>(p, n, gid, active, err);
+    const uint32_t ordw = agent_order<A, false>(p, n, active, err, blk);
 
     uint32_t gbits = 0;
 #pragma unroll 1

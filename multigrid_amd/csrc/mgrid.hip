@@ -475,34 +475,41 @@ __device__ __forceinline__ void wait_chunk(ChunkIn& in) {
                : "memory");
 }
 
-// "random actions" of the synthetic rollouts: uniform in [0,6] per agent, 3 bits each; also
-// stored to actions_out in the layout mg_step reads.
+// ONE Philox block per free-running env-step (round 3; it used to be two).  Words x, y, z of the block keyed P_ORDER feed
+// the Fisher-Yates of the agent order (A - 1 draws); word w feeds the "random actions" of the synthetic rollouts: agent a's
+// action is the a-th base-7 digit of w / 2^32 — multiply-high by 7, carry on with the low half of the product.  7 is odd, so
+// the low half is as uniform as w, and A <= 4 digits (7^4 << 2^32) are as exact as one multiply-high each.  Five agents need
+// all four words for the order; their actions are the five digits of word x of a second block (P_ACTION).  The order of a step
+// that draws no actions (mg_step, mg_step_replay) is unchanged by this.
+__device__ __forceinline__ U4 step_block(const Params& p, uint32_t gid, int purpose) {
+  return philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), (uint32_t)purpose << 28, p.seed_lo, p.seed_hi);
+}
+
+// uniform in [0,6] per agent, 3 bits each; also stored to actions_out in the layout mg_step reads.
 template <int A>
-__device__ __forceinline__ uint32_t draw_actions(const Params& p, int64_t n, uint32_t gid, bool active) {
-  const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), (uint32_t)P_ACTION << 28, p.seed_lo, p.seed_hi);
-  const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+__device__ __forceinline__ uint32_t draw_actions(const Params& p, int64_t n, uint32_t gid, bool active, const U4& blk) {
+  uint32_t w = A > 4 ? step_block(p, gid, P_ACTION).x : blk.w;
   uint32_t actw = 0;
 #pragma unroll
-  for (int a = 0; a < A && a < 4; ++a) actw |= __umulhi(rr[a], 7u) << (3 * a);
-  if (A > 4) {   // a second draw (counter word + 1) for the fifth agent
-    const U4 r2 = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), ((uint32_t)P_ACTION << 28) | 1u, p.seed_lo, p.seed_hi);
-    actw |= __umulhi(r2.x, 7u) << 12;
+  for (int a = 0; a < A; ++a) {
+    actw |= __umulhi(w, 7u) << (3 * a);
+    w *= 7u;
   }
   if (p.actions_out && active) {
-    uint32_t w = 0;
+    uint32_t o = 0;
 #pragma unroll
-    for (int a = 0; a < A && a < 4; ++a) w |= ((actw >> (3 * a)) & 7u) << (8 * a);
-    p.actions_out[n * kSlotWords<A>] = w;
+    for (int a = 0; a < A && a < 4; ++a) o |= ((actw >> (3 * a)) & 7u) << (8 * a);
+    p.actions_out[n * kSlotWords<A>] = o;
     if (A > 4) p.actions_out[n * kSlotWords<A> + 1] = (actw >> 12) & 7u;
   }
   return actw;
 }
 
 // Agent order of this step (multigrid.py:973-974), packed kOrdBits<A> bits per slot (2; 3 for five agents):
-// injected, or a Philox Fisher-Yates.
+// injected, or a Fisher-Yates on the step's Philox block.
 template <int A> constexpr int kOrdBits = A > 4 ? 3 : 2;
 template <int A, bool FAST>
-__device__ __forceinline__ uint32_t agent_order(const Params& p, int64_t n, uint32_t gid, bool active, uint32_t& err) {
+__device__ __forceinline__ uint32_t agent_order(const Params& p, int64_t n, bool active, uint32_t& err, const U4& blk) {
   constexpr int OB = kOrdBits<A>;
   constexpr uint32_t OM = (1u << OB) - 1u;
   uint32_t ordw = 0;
@@ -520,8 +527,7 @@ __device__ __forceinline__ uint32_t agent_order(const Params& p, int64_t n, uint
     if (seen != (1u << A) - 1u) { if (active) err |= MG_ERR_BAD_ORDER; }
     else ordw = w;
   } else if (A > 1 && MG_ABL != 3) {
-    const U4 r = philox(gid, (uint32_t)p.t, (uint32_t)(p.t >> 32), (uint32_t)P_ORDER << 28, p.seed_lo, p.seed_hi);
-    const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+    const uint32_t rr[4] = {blk.x, blk.y, blk.z, blk.w};
     // Fisher-Yates from the top, as np.random.shuffle does: swap slots i and j = rand(i+1)
 #pragma unroll
     for (int i = A - 1, w = 0; i >= 1; --i, ++w) {
@@ -633,14 +639,19 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
       actw = 0;
 #pragma unroll
       for (int a = 0; a < A; ++a) actw |= min(((a < 4 ? w >> (8 * a) : w2 >> (8 * (a - 4)))) & 255u, 7u) << (3 * a);
-    } else if (ROLL || (!FAST && p.random_actions)) actw = draw_actions<A>(p, n, gid, active);
+    }
+    // ---- the step's one Philox block: agent order, and the actions of a synthetic rollout ------
+    const bool draw_act = ROLL ? (p.actions == nullptr) : (!FAST && p.random_actions != 0);      // wave-uniform
+    U4 blk = U4{0u, 0u, 0u, 0u};
+    if (MG_ABL != 3 && (draw_act || (A > 1 && (FAST || !p.order)))) blk = step_block(p, gid, P_ORDER);
+    if (draw_act) actw = draw_actions<A>(p, n, gid, active, blk);
     // ---- step_count += 1 (multigrid.py:968) ----------------------------------------------
     uint32_t step = (st & 0xFFFFu) + 1u;
     uint32_t dbits = st >> 16;
     if (step > 0xFFFFu) step = 0xFFFFu;
 
     // ---- agent order (multigrid.py:973-974), packed 2 bits per slot --------------------------
-    const uint32_t ordw = agent_order<A, FAST>(p, n, gid, active, err);
+    const uint32_t ordw = agent_order<A, FAST>(p, n, active, err, blk);
 
     // ---- step_one_agent in that order (multigrid.py:860-924), branch-free except respawn -----
     uint32_t gbits = 0;          // agents whose forward touched the goal this step
@@ -1431,10 +1442,13 @@ int launch_ep_stats(mg_handle* h, int op, const uint8_t* mask, int n_roll, const
   return MG_OK;
 }
 
+// dest (mutable-grid step launches only): this launch writes its obs / rewards / dir-done there instead of into the handle's
+// own buffers — a slot of a caller's trajectory (mg_rollout on these kinds).  The handle itself is not touched, so a
+// concurrent mg_get_buffers never sees a caller's pointers.
 int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, const int8_t* respawn,
            const int8_t* reset_spawn, const uint8_t* mask, int random_actions, uint8_t* actions_out,
            const int8_t* objdrop = nullptr, const int8_t* reset_gen = nullptr, const int8_t* scatter = nullptr,
-           int n_roll = 0, const mg_rollout_out* roll = nullptr) {
+           int n_roll = 0, const mg_rollout_out* roll = nullptr, const mg_rollout_out* dest = nullptr) {
   Params p;
   memset(&p, 0, sizeof(p));
   const mg_config& c = h->cfg;
@@ -1471,11 +1485,15 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   DeviceGuard g(h->device);
   if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
   if (h->dynamic) {
+    if (dest) {
+      if (h->full_obs) p.obs_full = dest->obs_image; else p.obs_image = dest->obs_image;
+      p.reward = dest->reward; p.dir_done = dest->dir_done;
+    }
     dyn_geometry(h, &nw, &grid, &lds);
     hipLaunchKernelGGL(h->dvar->fn[dyn_dec_index(h)], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
     HIP_TRY(hipGetLastError());
     if (op == OP_RESET) h->reset_epoch += 1;
-    return launch_ep_stats(h, op, mask, 0, nullptr);
+    return dest ? launch_ep_stats(h, op, mask, 1, dest) : launch_ep_stats(h, op, mask, 0, nullptr);
   }
   if (objdrop || reset_gen || scatter) return fail(MG_EINVAL, "objdrop / gen / scatter injection needs a mutable-grid handle");
   if (n_roll > 0) {
@@ -2092,29 +2110,26 @@ int mg_rollout(mg_handle* h, int32_t n_steps, const void* actions, const mg_roll
   if (!h->have_reset) return fail(MG_ESTATE, "mg_reset must be called before mg_rollout / mg_rollout_random");
   if (h->dynamic) {
     // Mutable-grid kinds have no fused kernel (their grids live in LDS for one step at a time): the same n_steps steps as n_steps
-    // launches of the step kernel, each writing straight into its trajectory slot; the last one writes the handle's own buffers,
-    // which are then copied into the last slot (same stream).  Same contract, one launch per step.
+    // launches of the step kernel, each writing straight into its trajectory slot (launch()'s `dest`); the last one writes the
+    // handle's own buffers, which are then copied into the last slot (same stream: one full-size obs / reward / dir-done copy
+    // per call, the price of leaving the handle exactly where n_steps single calls would).  Same contract, one launch per step.
     const mg_config& c = h->cfg;
     const size_t S = (size_t)h->stride, A = (size_t)c.n_agents;
     const size_t obs_b = h->full_obs ? S * c.width * c.height * 3 : A * S * c.view_size * c.view_size * 3;
     const size_t rew_b = A * S * (c.reward_dtype == MG_REWARD_F32 ? 4 : 8), dd_b = S * h->dd_bytes, act_b = S * MG_SLOTS(c.n_agents);
-    const mg_buffers saved = h->buf;
-    uint8_t* const saved_full = h->obs_full;
     int rc = MG_OK;
     for (int32_t k = 0; k < n_steps && rc == MG_OK; ++k) {
-      if (k < n_steps - 1) {
-        if (h->full_obs) h->obs_full = out->obs_image + k * obs_b; else h->buf.obs_image = out->obs_image + k * obs_b;
-        h->buf.reward = reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(out->reward) + k * rew_b);
-        h->buf.dir_done = out->dir_done + k * dd_b;
-      } else {
-        h->buf = saved; h->obs_full = saved_full;
-      }
+      mg_rollout_out slot;
+      memset(&slot, 0, sizeof(slot));
+      slot.obs_image = out->obs_image + k * obs_b;
+      slot.reward = reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(out->reward) + k * rew_b);
+      slot.dir_done = out->dir_done + k * dd_b;
       const uint8_t* act_k = actions ? static_cast<const uint8_t*>(actions) + k * act_b : nullptr;
       uint8_t* act_out = (!actions && out->actions) ? out->actions + k * act_b : nullptr;
-      rc = launch(h, OP_STEP, act_k, nullptr, nullptr, nullptr, nullptr, actions ? 0 : 1, act_out);
+      rc = launch(h, OP_STEP, act_k, nullptr, nullptr, nullptr, nullptr, actions ? 0 : 1, act_out, nullptr, nullptr, nullptr, 0, nullptr,
+                  k < n_steps - 1 ? &slot : nullptr);
       if (rc == MG_OK) h->t += 1;
     }
-    h->buf = saved; h->obs_full = saved_full;
     if (rc != MG_OK) return rc;
     DeviceGuard g(h->device);
     if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
@@ -2189,6 +2204,19 @@ int mg_get_step_index(mg_handle* h, uint64_t* out) {
 int mg_set_step_index(mg_handle* h, uint64_t t) {
   if (!h) return fail(MG_EINVAL, "null handle");
   h->t = t;
+  return MG_OK;
+}
+
+int mg_get_reset_index(mg_handle* h, uint64_t* out) {
+  if (!h || !out) return fail(MG_EINVAL, "null argument");
+  *out = h->reset_epoch;
+  return MG_OK;
+}
+
+int mg_set_reset_index(mg_handle* h, uint64_t n) {
+  if (!h) return fail(MG_EINVAL, "null handle");
+  if (n >> 63) return fail(MG_EINVAL, "reset index must be below 2^63");
+  h->reset_epoch = n;
   return MG_OK;
 }
 

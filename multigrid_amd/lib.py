@@ -87,6 +87,8 @@ SYMBOLS = {
     'mg_sync': (C.c_int, [C.c_void_p]),
     'mg_get_step_index': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     'mg_set_step_index': (C.c_int, [C.c_void_p, C.c_uint64]),
+    'mg_get_reset_index': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    'mg_set_reset_index': (C.c_int, [C.c_void_p, C.c_uint64]),
     'mg_check_errors': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     'mg_get_goal': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'mg_get_launch_info': (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 4),

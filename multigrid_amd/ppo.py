@@ -436,7 +436,7 @@ class BatchedController:
   def rollout(self, n_steps, use_graph=None):
     """run_episode (v8_robust_ppo.py:222-273) for N envs x n_steps, everything on device.
     Returns {'image' [T, A, N, V, V, 3], 'direction' [T, A, N], 'action', 'log_prob', 'value', 'reward' [T, A, N]
-    (float32 as at v8:311), 'done' [T, N]}.
+    (float64, like the Python floats v8's compute_gae runs on, v8:275-293; advantages() casts afterwards as v8:309-311 do), 'done' [T, N]}.
 
     use_graph (default: on for CUDA devices): the per-step policy work — one stacked forward, sampling, the action
     write and the trajectory stores — is launch-bound at these sizes, so it is captured once into two HIP graphs and
@@ -454,7 +454,7 @@ class BatchedController:
       env.actions[:N, :A] = act.t().to(torch.uint8)
       env.step()
       for k, v in (('image', img), ('direction', d), ('action', act), ('log_prob', logp), ('value', val),
-                   ('reward', env.reward.float().clone()), ('done', env.done.clone())):   # v8 casts to float32 too (v8:311)
+                   ('reward', env.reward.double().clone()), ('done', env.done.clone())):
         buf[k].append(v)
     return {k: torch.stack(v) for k, v in buf.items()}
 
@@ -469,7 +469,7 @@ class BatchedController:
              'action': torch.zeros((n_steps, A, N), dtype=torch.long, device=dev),
              'log_prob': torch.zeros((n_steps, A, N), device=dev),
              'value': torch.zeros((n_steps, A, N), device=dev),
-             'reward': torch.zeros((n_steps, A, N), device=dev),
+             'reward': torch.zeros((n_steps, A, N), dtype=torch.float64, device=dev),
              'done': torch.zeros((n_steps, N), dtype=torch.uint8, device=dev)}
       t_idx = torch.zeros(1, dtype=torch.long, device=dev)
 
@@ -480,8 +480,8 @@ class BatchedController:
         for k, v in (('image', img), ('direction', d), ('action', act), ('log_prob', logp), ('value', val)):
           buf[k].index_copy_(0, t_idx, v.unsqueeze(0))
 
-      def post():     # after the env kernel: rewards (float32 as at v8:311) and done of the step, then t += 1
-        buf['reward'].index_copy_(0, t_idx, env.reward.float().unsqueeze(0))
+      def post():     # after the env kernel: rewards (float64: GAE runs on them uncast, v8:275-293) and done of the step, then t += 1
+        buf['reward'].index_copy_(0, t_idx, env.reward.double().unsqueeze(0))
         buf['done'].index_copy_(0, t_idx, env.done.unsqueeze(0))
         t_idx.add_(1)
 

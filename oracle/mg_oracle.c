@@ -855,16 +855,18 @@ void mgo_step_ex(mgo_env* e, const int* actions, const uint8_t* order, const int
   if (done_out) *done_out = (uint8_t)collective_done;
 }
 
-/* Philox action draw for synthetic rollouts: uniform in [0,6] */
+/* Philox action draw for synthetic rollouts: uniform in [0,6].  One block per env-step: the actions are the base-7
+ * digits of word 3 of the SAME block the agent order is drawn from (words 0..2, see mgo_step_ex) - digit a = multiply-high
+ * by 7, carry on with the low half of the product.  Five agents use all four words for the order; their actions are the
+ * five digits of word 0 of a second block (P_ACTION). */
 void mgo_random_actions(const mgo_env* e, uint64_t t, int* actions) {
-  uint32_t ctr[4] = {(uint32_t)e->gid, (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)P_ACTION << 28};
+  uint32_t ctr[4] = {(uint32_t)e->gid, (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)(e->A > 4 ? P_ACTION : P_ORDER) << 28};
   uint32_t key[2] = {(uint32_t)e->seed, (uint32_t)(e->seed >> 32)}, r[4];
   philox4x32_10(ctr, key, r);
-  for (int a = 0; a < e->A && a < 4; ++a) actions[a] = (int)mulhi32(r[a], 7u);
-  if (e->A > 4) {                                        /* a second block (counter word + 1) for agents 4.. */
-    ctr[3] |= 1u;
-    philox4x32_10(ctr, key, r);
-    for (int a = 4; a < e->A; ++a) actions[a] = (int)mulhi32(r[a - 4], 7u);
+  uint32_t w = e->A > 4 ? r[0] : r[3];
+  for (int a = 0; a < e->A; ++a) {
+    actions[a] = (int)mulhi32(w, 7u);
+    w *= 7u;
   }
 }
 

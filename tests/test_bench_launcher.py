@@ -34,6 +34,20 @@ def test_gpus_flag_alone_starts_the_ranks():
   assert d['n_gpus'] == 2 and d['config']['global_envs'] == 2000 and d['config']['env_id_base_of_last_rank'] == 1000
   # max over ranks: rank 1 sleeps 2 ms per step
   assert d['ms_per_step'] >= 2.0
+  # the line proves who took part: one record per rank, the process group's own size and backend, distinct devices
+  assert [r['rank'] for r in d['ranks']] == [0, 1] and d['ranks'][1]['kernel_ms'] >= 2.0 > d['ranks'][0]['kernel_ms'] >= 1.0
+  assert d['distributed'] == {'backend': 'gloo', 'world_size': 2, 'distinct_devices': 2}
+
+
+def test_ranks_that_share_a_device_are_an_error_outside_a_rehearsal():
+  sys.path.insert(0, ROOT)
+  import bench
+  two = [{'rank': 0, 'pci_bus_id': '0000:05:00'}, {'rank': 1, 'pci_bus_id': '0000:05:00'}]
+  with pytest.raises(SystemExit) as e:
+    bench.check_distinct_devices(two, allow_shared=False)
+  assert '0000:05:00' in str(e.value)
+  assert bench.check_distinct_devices(two, allow_shared=True) == 1
+  assert bench.check_distinct_devices([two[0], {'rank': 1, 'pci_bus_id': '0000:15:00'}], allow_shared=False) == 2
 
 
 def test_world_size_that_disagrees_with_the_flag_is_an_error():
@@ -57,3 +71,7 @@ def test_two_ranks_on_one_card_real_bench():
   assert d['device_errors'] == 0 and d['value'] > 0
   assert d['rollout']['device_errors'] == 0 and d['rollout']['env_steps_timed'] == 24 and d['rollout']['value'] > 0
   assert 0.0 < d['config']['auto_reset']['env_steps_reset_in_timed_region_frac'] < 0.05
+  # two records, both naming the one card (a declared rehearsal: the same PCI bus id is allowed), each with its own kernel time
+  assert [r['rank'] for r in d['ranks']] == [0, 1] and d['ranks'][0]['pci_bus_id'] == d['ranks'][1]['pci_bus_id'] is not None
+  assert all(r['kernel_ms'] > 0 and r['device'] and r['compute_units'] > 0 for r in d['ranks'])
+  assert d['distributed'] == {'backend': 'gloo', 'world_size': 2, 'distinct_devices': 1, 'shared_device_rehearsal': True}

@@ -408,6 +408,51 @@ def _random_layouts(rng, n, W, H, with_objects=True):
   return cells
 
 
+def test_set_maps_and_rollout_on_the_handles_own_stream():
+  """use_torch_stream=False: the library launches on its own non-blocking stream while the tensors handed to set_maps() and
+  rollout(actions) are produced by torch kernels on torch's stream (round-2 advisor finding: the import kernel could read a
+  layout tensor still being written, and the temporary was only kept alive against torch's stream).  The layouts come out of a
+  long chain of torch kernels here, so an unordered import would read them early; parity with the oracle holding the final
+  layouts shows it did not."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  from multigrid_amd import layouts
+  W = H = 9
+  A, V, n, max_steps = 3, 5, 600, 30
+  rng = np.random.default_rng(5)
+  cells = _random_layouts(rng, n, W, H, True)
+  env = BatchedMultiGrid(layouts.empty_bordered(W, H, goal=(W - 2, H - 2)), n_envs=n, n_agents=A, view_size=V, max_steps=max_steps,
+                         seed=9, use_torch_stream=False)
+  dev = env.device
+  junk = torch.full((n, H, W, 3), 2, dtype=torch.uint8, device=dev)
+  big = torch.randn(4096, 4096, device=dev)
+  for _ in range(6):                                # keep torch's stream busy ...
+    big = big @ big * 1e-3
+  t = junk.clone()
+  t.copy_(torch.from_numpy(cells).to(dev))          # ... and write the real layouts behind that work
+  env.set_maps(t)
+  del t
+  orc = c_oracle.OracleBatch(cells[0], n, W=W, H=H, A=A, V=V, max_steps=max_steps, shaping=1, auto_reset=1, seed=9)
+  orc.set_maps(cells)
+  env.reset()
+  orc.reset()
+  env.sync()
+  _cmp(env, orc, 'reset', step=False)
+  acts = rng.integers(0, 7, size=(40, n, A)).astype(np.uint8)
+  for _ in range(3):
+    big = big @ big * 1e-3
+  traj = env.rollout(torch.from_numpy(acts).to(dev))      # the action ring is built by torch kernels right before the launch
+  env.sync()
+  for k in range(40):
+    pad = np.full((A, orc.stride), 6, np.uint8)          # the oracle takes actions agent-major over the padded batch
+    pad[:, :n] = acts[k].T
+    orc.step(pad)
+    assert np.array_equal(traj['image'][k].cpu().numpy().reshape(A, n, -1), orc.obs_image[:, :n]), k
+    assert np.array_equal(traj['reward'][k].cpu().numpy().view(np.int64), orc.reward[:, :n].view(np.int64)), k
+  assert env.check_errors() == 0 and orc.errors() == 0
+  env.close()
+
+
 @pytest.mark.parametrize('W,H,A,V,objects,grid', [(9, 9, 3, 5, True, 0), (8, 7, 2, 7, True, 0), (15, 15, 3, 5, False, 0), (9, 9, 3, 5, True, 2)])
 def test_per_env_maps_parity(monkeypatch, W, H, A, V, objects, grid):
   """mg_set_maps: every env resets to its OWN layout (the batched form of N reference envs built on N different fixed maps)

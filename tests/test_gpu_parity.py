@@ -495,7 +495,17 @@ def test_two_resets_in_a_row_redraw(cluttered_cells):
   mask = np.zeros(orc.stride, np.uint8); mask[::2] = 1
   env.reset(mask=torch.from_numpy(mask).to(env.device)); orc.reset(mask=mask)
   _cmp(env, orc, 'masked reset')
-  env.close()
+  # the reset counter is part of the handle's generator state (mg_get/set_reset_index): it counts CALLS (three so far, the
+  # masked one included), and a fresh handle given the same (step index, reset index) redraws what this one draws next
+  assert env.reset_index == 3 and env.step_index == 1
+  twin, _ = _make(cluttered_cells, n, seed=77, max_steps=1)
+  twin.reset_index, twin.step_index = env.reset_index, env.step_index
+  env.reset(); twin.reset(); orc.reset()
+  _cmp(env, orc, 'reset 4')
+  assert torch.equal(env.agent_state, twin.agent_state) and torch.equal(env.obs_image, twin.obs_image) and twin.reset_index == 4
+  with pytest.raises(Exception, match='2\\^63'):
+    twin.reset_index = 1 << 63
+  env.close(); twin.close()
 
 
 def test_default_make_is_the_unshaped_reference_env():

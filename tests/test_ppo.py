@@ -465,7 +465,7 @@ def test_graph_rollout_is_self_consistent():
     acts = traj['action'][t]
     assert int(acts.min()) >= 0 and int(acts.max()) <= 6
     twin.step(acts)
-    assert torch.equal(traj['reward'][t], twin.reward.float()), t
+    assert traj['reward'].dtype == torch.float64 and torch.equal(traj['reward'][t], twin.reward), t   # float64: GAE runs on them uncast (v8:275-293)
     assert torch.equal(traj['done'][t], twin.done), t
   # a second graphed rollout continues from where the first stopped, and an update runs on its output
   traj = ctl.rollout(T, use_graph=True)
