@@ -218,7 +218,7 @@ def main():
     # and for per-env grids: carry r/w + grid rows r/w (+ aux r/w)
     b_alg = B_ALG_PER_ENV_STEP if headline else (
         (env.width * env.height * 3 if env.obs_full is not None else A * V * V * 3) + (4 if A < 4 else 8) + 8 * A + env.slots +
-        8 * (A + 1) + ((2 * env.slots + 8 * env.grid_words) if env.mutable_grid else 0) + (32 if env.aux is not None else 0))
+        8 * (A + 1) + ((2 * env.slots + 8 * ((env.width * env.height + 3) // 4)) if env.mutable_grid else 0) + (32 if env.aux is not None else 0))
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     ring = torch.randint(0, 7, (ACTION_RING, env.stride, env.slots), dtype=torch.uint8, device=dev, generator=gen)

@@ -188,11 +188,12 @@ typedef struct mg_buffers {
   /* mutable-grid handles only (mutable_grid != 0), NULL / 0 otherwise: */
   uint32_t* carry;       /* [env_stride] (five agents: [env_stride][2]): byte a = kind id of the object agent a carries,
                             0 = nothing (multigrid.py:490, 926-951) */
-  uint32_t* grid;        /* bytes [env_stride/64][grid_words*4][64]: the library's cell code (see MG_KIND_ID) of cell ci = y*W + x of env n at byte
-                            ((n/64)*grid_words*4 + ci)*64 + n%64 (cells >= W*H are padding).  Cell-major within a 64-env
-                            chunk, so a wavefront moves its chunk between HBM and LDS as fully coalesced rows and a lane's
-                            LDS address is linear in the cell index; use mg_export_grid for a plain [n][H*W] copy. */
-  int32_t  grid_words;   /* ceil(W*H/4) */
+  uint32_t* grid;        /* dwords [env_stride/64][grid_words/4][64][4]: the library's cell codes (see MG_KIND_ID), cell-major
+                            within a 64-env chunk.  With l = n%64, D = 16*ci + l/4, k = D/64, L = D%64, the code of cell
+                            ci = y*W + x of env n is byte l%4 of dword ((n/64)*(grid_words/4) + k/4)*256 + L*4 + k%4
+                            (cells >= W*H are padding): a wavefront moves its chunk between HBM and LDS as fully
+                            coalesced 16-byte vectors.  Use mg_export_grid for a plain [n][H*W] copy. */
+  int32_t  grid_words;   /* dwords per env in `grid`: ceil(W*H/4) rounded up to a multiple of 4 */
   int32_t  mutable_grid;
   uint32_t* aux;         /* MEETUP, CLUTTERED, FOURROOMS, [env_stride][4]: words 0..2 = MeetupEnv.goal_pos, two per word
                             (goal 2k in bits 0..15 of word k, goal 2k+1 in bits 16..31, each x | y<<6, 0xFFFF if unused:

@@ -115,7 +115,7 @@ class BatchedMultiGrid:
     if self.mutable_grid:
       self.grid_words = int(b.grid_words)
       self.carry = _alias(b.carry, (S,) if A <= 4 else (S, 2), '<i4', dev)[:n]   # byte a = kind agent a carries
-      self.grid_blocked = _alias(b.grid, (S // 64, self.grid_words * 4, 64), '|u1', dev)  # [chunk][cell][lane], include/mgrid.h
+      self.grid_blocked = _alias(b.grid, (S // 64, self.grid_words // 4, 64, 16), '|u1', dev)  # [chunk][row group][lane][16 B], include/mgrid.h
 
   def _order_behind_torch(self):
     """The library launches on the handle's stream; tensors handed to it were produced on torch's CURRENT stream.  When the

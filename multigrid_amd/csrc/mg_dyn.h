@@ -4,10 +4,11 @@
 // Params, Philox, the agent-order / action draws, the v8 shaper and the obs staging with the
 // shared-map kernel.
 //
-// Every env owns a W*H grid of one-byte kind ids (include/mgrid.h MG_KIND_ID) plus one "carry" word
-// (byte a = what agent a carries).  HBM keeps the grids chunk-blocked and cell-major,
-// [chunk][cell y*W+x][64 lanes] bytes, so a wavefront moves its 64 envs' grids to and from LDS as
-// fully coalesced dword rows.  In LDS the wave's grids are padded by one ring of grey walls,
+// Every env owns a W*H grid of one-byte cell codes (below) plus one "carry" word
+// (byte a = what agent a carries).  HBM keeps the grids chunk-blocked and cell-major: logically
+// [chunk][cell y*W+x][64 lanes] bytes, i.e. dword rows of 64 lanes (row k, lane L = lanes 4(L%16).. of cell L/16 + 4k);
+// four consecutive rows of a lane are stored side by side ([chunk][k/4][L][k%4] dwords, grid_byte()), so a wavefront
+// moves its 64 envs' grids to and from LDS as fully coalesced 16-byte vectors, a quarter of the instructions dword rows took.  In LDS the wave's grids are padded by one ring of grey walls,
 // [(H+2)*(W+2) cells][68 bytes: 64 lanes + 4 pad]: a lane's byte address is LINEAR in the cell
 // coordinates (cell*68 + lane), so a view cell costs one add + one byte read, cells outside the
 // grid are reached by clamping the coordinate onto the ring (Grid.slice pads with the same grey
@@ -265,19 +266,32 @@ template <int A> using carry_t = typename CarryOf<A>::type;
 template <int A, int PRE>
 struct DynIn {
   uint32_t st[A + 1 > 4 ? A + 1 : 4];   // env_state words (A + 1 used)
+  u32x4 q;                              // A == 3: the same four words, fetched as one 16-byte vector
   uint32_t carry, act;
   uint32_t carry2, act2;    // five agents only: the second dword of the carry word / of the action slots
   uint32_t aux[4];          // MEETUP: goal positions and past distances
-  uint32_t pre[PRE];        // this lane's share of the chunk's grid rows (dword lane + 64k), GW <= PRE only
+  u32x4 pre4[PRE / 4];      // this lane's share of the chunk's grid rows (rows 4b..4b+3 of lane L), GW <= PRE only
 };
+
+// byte of (cell ci, lane l) inside a chunk's grid block (see the layout at the top of this file)
+__host__ __device__ inline int64_t grid_byte(int ci, int l) {
+  const int D = ci * 16 + (l >> 2), k = D >> 6, L = D & 63;
+  return ((((int64_t)(k >> 2) * 64 + L) * 4 + (k & 3)) << 2) + (l & 3);
+}
 
 template <int A, int PRE>
 __device__ __forceinline__ void dyn_load(const Params& p, int64_t env0, int lane, DynIn<A, PRE>& in) {
   const int64_t n = env0 + lane;
 #pragma unroll
   for (int a = 0; a < (A + 1 > 4 ? A + 1 : 4); ++a) in.st[a] = 0u;
+  in.q = u32x4{0, 0, 0, 0};
+  if constexpr (A == 3) {
+    const void* ptr = reinterpret_cast<const uint4*>(p.env_state) + n;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(in.q) : "v"(ptr) : "memory");
+  } else {
 #pragma unroll
-  for (int a = 0; a <= A; ++a) in.st[a] = asm_load_u32(p.env_state + n * (A + 1) + a);
+    for (int a = 0; a <= A; ++a) in.st[a] = asm_load_u32(p.env_state + n * (A + 1) + a);
+  }
   in.carry = asm_load_u32(p.carry + n * kSlotWords<A>);
   in.act = in.act2 = 0x06060606u;
   in.carry2 = 0u;
@@ -291,18 +305,26 @@ __device__ __forceinline__ void dyn_load(const Params& p, int64_t env0, int lane
     in.aux[k] = 0u;
     if (p.aux) in.aux[k] = asm_load_u32(p.aux + n * 4 + k);
   }
-  const uint32_t* ghbm = p.grid + (env0 >> 6) * (int64_t)p.GW * kWave + lane;
+  const uint4* ghbm = reinterpret_cast<const uint4*>(p.grid) + ((env0 >> 6) * (int64_t)p.GB * kWave + lane);
 #pragma unroll
-  for (int k = 0; k < PRE; ++k) {
-    in.pre[k] = 0u;
-    if (k < p.GW && p.GW <= PRE) in.pre[k] = asm_load_u32(ghbm + k * kWave);
+  for (int b = 0; b < PRE / 4; ++b) {
+    // every load is issued (a branch around one would leave the compiler a phi to resolve with copies of a register
+    // whose load is still in flight); the ones past the grid re-read the chunk's first vector, which the L2 holds
+    const void* ptr = (b < p.GB && p.GW <= PRE) ? ghbm + b * kWave : ghbm;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(in.pre4[b]) : "v"(ptr) : "memory");
   }
 }
 
 template <int A, int K, int PRE>
 __device__ __forceinline__ void dyn_wait(DynIn<A, PRE>& in) {
   static_assert(A <= 5 && PRE % 16 == 0, "operand lists below");
-  if constexpr (A <= 3) {
+  if constexpr (A == 3) {
+    asm volatile("s_waitcnt vmcnt(%7)"
+                 : "+v"(in.q), "+v"(in.carry), "+v"(in.act), "+v"(in.aux[0]), "+v"(in.aux[1]), "+v"(in.aux[2]), "+v"(in.aux[3])
+                 : "n"(K)
+                 : "memory");
+    in.st[0] = in.q.x; in.st[1] = in.q.y; in.st[2] = in.q.z; in.st[3] = in.q.w;
+  } else if constexpr (A <= 2) {
     asm volatile("s_waitcnt vmcnt(%10)"
                  : "+v"(in.st[0]), "+v"(in.st[1]), "+v"(in.st[2]), "+v"(in.st[3]),
                    "+v"(in.carry), "+v"(in.act), "+v"(in.aux[0]), "+v"(in.aux[1]), "+v"(in.aux[2]), "+v"(in.aux[3])
@@ -324,14 +346,8 @@ __device__ __forceinline__ void dyn_wait(DynIn<A, PRE>& in) {
   }
   // the grid rows: volatile asm statements keep their order, so no use of these registers can move above the wait
 #pragma unroll
-  for (int k = 0; k < PRE; k += 16)
-    asm volatile(""
-                 : "+v"(in.pre[k]), "+v"(in.pre[k + 1]), "+v"(in.pre[k + 2]), "+v"(in.pre[k + 3]), "+v"(in.pre[k + 4]),
-                   "+v"(in.pre[k + 5]), "+v"(in.pre[k + 6]), "+v"(in.pre[k + 7]), "+v"(in.pre[k + 8]), "+v"(in.pre[k + 9]),
-                   "+v"(in.pre[k + 10]), "+v"(in.pre[k + 11]), "+v"(in.pre[k + 12]), "+v"(in.pre[k + 13]),
-                   "+v"(in.pre[k + 14]), "+v"(in.pre[k + 15])
-                 :
-                 : "memory");
+  for (int b = 0; b < PRE / 4; b += 4)
+    asm volatile("" : "+v"(in.pre4[b]), "+v"(in.pre4[b + 1]), "+v"(in.pre4[b + 2]), "+v"(in.pre4[b + 3]) : : "memory");
 }
 
 // MeetupEnv.get_dist (meetup.py:78-84): Manhattan distance of every agent to the goal whose summed
@@ -420,38 +436,68 @@ __device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uin
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// -DMG_PHASE_TIMERS (timing-only builds, tools/gpu.sh build ... ; never the product): where a wave's time goes.  The shader
+// clock (s_memtime) is read between the phases of a chunk and the differences are summed over all waves into g_phase[],
+// which mg_debug_phase_counters hands to tools/kbench.  Wall cycles of the wave, stalls included — the phase breakdown
+// rocprofv3's PC sampling would give, which this pool does not offer.
+#ifdef MG_PHASE_TIMERS
+constexpr int kPhaseWaves = 8192, kPhases = 12;      // one row of counters per wave of the launch: no atomics, nothing shared
+static __device__ unsigned int g_phase[kPhaseWaves * kPhases];
+#define MG_PH_PARAM , uint32_t (&ph_acc)[kPhases]
+#define MG_PH_ARG , ph_acc
+#define MG_PH_BEGIN() uint64_t ph_t = __builtin_amdgcn_s_memtime()
+#define MG_PH(i) do { const uint64_t ph_now = __builtin_amdgcn_s_memtime(); ph_acc[i] += (uint32_t)(ph_now - ph_t); ph_t = ph_now; } while (0)
+#else
+#define MG_PH_PARAM
+#define MG_PH_ARG
+#define MG_PH_BEGIN() do {} while (0)
+#define MG_PH(i) do {} while (0)
+#endif
+
 // One chunk (64 envs) of one step()/reset() on mutable grids.
 template <int A, int V, bool FULL, int PRE, bool DEC>
 __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, const uint32_t* lut, const uint32_t* base,
                                           const uint16_t* pidx, const uint16_t* cpc, uint32_t* stage, uint32_t* gw, int lane,
-                                          int64_t env0, const DynIn<A, PRE>& in, uint32_t& err_acc) {
+                                          int64_t env0, const DynIn<A, PRE>& in, uint32_t& err_acc MG_PH_PARAM) {
   constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
   const int64_t n = env0 + lane;
   const bool active = n < p.n_envs;
   const uint32_t gid = (uint32_t)(p.gid_base + (uint64_t)n);
   const uint32_t all = (1u << A) - 1u;
   const int cells = p.W * p.H;
+  MG_PH_BEGIN();
 
   // ---- this wave's 64 grids: HBM rows -> padded LDS grid.  Dword d = lane + 64k of the chunk holds
   //      lanes 4*(d%16)..+3 of cell d/16; it goes to LDS dword pidx[cell]*17 + d%16. ---------------
-  uint32_t* const ghbm = p.grid + (env0 >> 6) * (int64_t)p.GW * kWave;
+  uint4* const ghbm = reinterpret_cast<uint4*>(p.grid) + (env0 >> 6) * (int64_t)p.GB * kWave;   // this chunk's grid block
   const int l4 = lane & 15, c4 = lane >> 4;
+  // LDS dword of cell ci = y*W + x for this lane's four envs: ((y+1)(W+2) + x+1)*17 + l4 = (ci + 2y + W+3)*17 + l4, with
+  // y = ci / W as one 24-bit multiply and a shift (inv_w20 = ceil(2^20 / W): exact for ci < 2^20 / W, i.e. any grid here).
+  // Arithmetic, not the pidx[] table: a table lookup per row is a dependent LDS round trip per row (round 3 phase timers:
+  // a quarter of a Cluttered-15x15 chunk went into this copy).
+  const int ldw0 = __mul24(p.W + 3, kCellW) + l4;
+  auto lds_dword = [&](int ci) { return __mul24(ci + 2 * (int)(__umul24((uint32_t)ci, (uint32_t)p.inv_w20) >> 20), kCellW) + ldw0; };
   if (p.GW <= PRE) {
+    // The addresses are loop-invariant: with 16 rows the compiler keeps them in registers across chunks (free), with 64
+    // rows that would spill, so there the lane's first cell passes through an empty asm and they are recomputed per chunk.
+    int c4v = c4;
+    if (PRE > 16) asm volatile("" : "+v"(c4v));
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
-      const int ci = c4 + 4 * k;
-      if (k < p.GW && ci < cells) gw[(int)pidx[ci] * kCellW + l4] = in.pre[k];
+      const int ci = c4v + 4 * k;
+      if (ci < cells) gw[lds_dword(ci)] = in.pre4[k >> 2][k & 3];          // (ci < cells <= 4 GW: no row past the grid)
     }
   } else {
     // grids beyond the prefetch registers: rows fetched kPreMax at a time (all loads of a batch in flight together)
     for (int k0 = 0; k0 < p.GW; k0 += kPreMax) {
-      uint32_t row[kPreMax];
+      uint4 row[kPreMax / 4];
 #pragma unroll
-      for (int j = 0; j < kPreMax; ++j) row[j] = (k0 + j < p.GW) ? ghbm[(k0 + j) * kWave + lane] : 0u;
+      for (int j = 0; j < kPreMax / 4; ++j) row[j] = (k0 / 4 + j < p.GB) ? ghbm[(k0 / 4 + j) * kWave + lane] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
       for (int j = 0; j < kPreMax; ++j) {
         const int ci = c4 + 4 * (k0 + j);
-        if (k0 + j < p.GW && ci < cells) gw[(int)pidx[ci] * kCellW + l4] = row[j];
+        const uint4 r = row[j >> 2];
+        if (ci < cells) gw[lds_dword(ci)] = (j & 3) == 0 ? r.x : (j & 3) == 1 ? r.y : (j & 3) == 2 ? r.z : r.w;
       }
     }
   }
@@ -459,6 +505,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  MG_PH(0);      // grid rows -> LDS
   uint8_t* const g = reinterpret_cast<uint8_t*>(gw) + lane;
   bool dirty = false;            // this env's grid changed: the wave's rows go back to HBM only if some lane's did
   auto gs = [&](int off, uint32_t k) { g_set(g, off, k); dirty = true; };
@@ -499,6 +546,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     uint32_t dbits = (st >> 16) & all;
     if (step > 0xFFFFu) step = 0xFFFFu;
     const uint32_t ordw = agent_order<A, false>(p, n, active, err, blk);
+    MG_PH(1);    // unpack, actions, order (Philox)
 
     uint32_t gbits = 0;
 #pragma unroll 1
@@ -569,6 +617,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
       if (act > 6u) err |= MG_ERR_BAD_ACTION;                                   // assert False :902
       pd = pd_set(pd, a, npd);
     }
+    MG_PH(2);    // step_one_agent x A
     double rgoal = 0.0;
     if (gbits) rgoal = device_reward(step, p.max_steps);                        // _reward() :883
     done_flag = (p.competitive && dbits != 0u) || (step >= (uint32_t)p.max_steps);   // :986-993
@@ -609,12 +658,13 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     }
   }
 
+  MG_PH(3);      // rewards, shaper, reward stores
   // ---- reset() (multigrid.py:466-501) / auto-reset: _gen_grid on this env's own grid ------------
   const bool do_reset = (!is_step) ? (p.mask ? (p.mask[active ? n : 0] != 0) : true) : (done_flag && p.auto_reset);
   if (do_reset) {
     if (p.grid0) {                         // mg_set_maps: this env's own layout (a lane's byte of every cell row)
-      const uint8_t* t0 = reinterpret_cast<const uint8_t*>(p.grid0 + (env0 >> 6) * (int64_t)p.GW * kWave) + lane;
-      for (int ci = 0; ci < cells; ++ci) gs((int)pidx[ci] * kCellB, t0[ci * kWave]);
+      const uint8_t* t0 = reinterpret_cast<const uint8_t*>(p.grid0) + (env0 >> 6) * (int64_t)p.GB * (kWave * 16);
+      for (int ci = 0; ci < cells; ++ci) gs((int)pidx[ci] * kCellB, t0[grid_byte(ci, lane)]);
     } else {
       for (int ci = 0; ci < cells; ++ci) gs((int)pidx[ci] * kCellB, (base[ci >> 2] >> (8 * (ci & 3))) & 255u);
     }
@@ -718,10 +768,15 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     st = dk_bits;
   }
 
+  MG_PH(4);      // reset / auto-reset
   if (active) {
+    if constexpr (A == 3) {          // the four words of an env are one aligned 16-byte vector
+      reinterpret_cast<uint4*>(p.env_state)[n] = make_uint4(shw[0] | pd_get(pd, 0), shw[1] | pd_get(pd, 1), shw[2] | pd_get(pd, 2), st);
+    } else {
 #pragma unroll
-    for (int a = 0; a < A; ++a) p.env_state[n * (A + 1) + a] = shw[a] | pd_get(pd, a);
-    p.env_state[n * (A + 1) + A] = st;
+      for (int a = 0; a < A; ++a) p.env_state[n * (A + 1) + a] = shw[a] | pd_get(pd, a);
+      p.env_state[n * (A + 1) + A] = st;
+    }
     p.carry[n * kSlotWords<A>] = carry_to_kinds((uint32_t)carry);
     if constexpr (A > 4) p.carry[n * kSlotWords<A> + 1] = carry_to_kinds((uint32_t)(carry >> 32));
     if (p.aux) reinterpret_cast<uint4*>(p.aux)[n] = make_uint4(goal[0], goal[1], goal[2], past);
@@ -737,13 +792,38 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (__builtin_amdgcn_ballot_w64(dirty) != 0ull) {          // wave-uniform
-#pragma unroll 4
-    for (int k = 0; k < p.GW; ++k) {
-      const int ci = c4 + 4 * k;
-      if (ci < cells) ghbm[k * kWave + lane] = gw[(int)pidx[ci] * kCellW + l4];
+    if (p.GW <= PRE) {
+      // the mirror of the copy-in, unrolled the same way: the same (kept or recomputed) addresses, every LDS read of
+      // the grid in flight before the first store
+      int c4v = c4;
+      if (PRE > 16) asm volatile("" : "+v"(c4v));
+#pragma unroll
+      for (int b = 0; b < PRE / 4; ++b) {
+        if (b < p.GB) {                                       // rows 4b .. 4b+3 of this lane as one 16-byte store
+          uint32_t r[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ci = c4v + 4 * (4 * b + j);
+            r[j] = ci < cells ? gw[lds_dword(ci)] : 0u;
+          }
+          ghbm[b * kWave + lane] = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+      }
+    } else {
+#pragma unroll 2
+      for (int b = 0; b < p.GB; ++b) {
+        uint32_t r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ci = c4 + 4 * (4 * b + j);
+          r[j] = ci < cells ? gw[lds_dword(ci)] : 0u;
+        }
+        ghbm[b * kWave + lane] = make_uint4(r[0], r[1], r[2], r[3]);
+      }
     }
   }
 
+  MG_PH(5);      // state stores, grid rows -> HBM
   // ---- gen_obs (multigrid.py:1037-1067) --------------------------------------------------------
 #if MG_ABL != 2
   if (FULL) {
@@ -768,11 +848,14 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 #else
       dyn_view<V, DEC>(p, g, lut, pd_get(pd, a), (uint32_t)(carry >> (8 * a)) & 255u, s, vm);
 #endif
+      MG_PH(6);  // views
       emit_obs<A, V, DEC>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB, ((p.nt_obs >> a) & 1) != 0,
                           nullptr, doorw);
+      MG_PH(7);  // staging + obs stores
     }
   }
 #endif
+  MG_PH(8);
 }
 
 template <int A, int V, bool FULL, int PRE, bool DEC>
@@ -821,28 +904,46 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up t
 #else
   constexpr int kObs = 0;
 #endif
-  constexpr int kLo = (kObs + A + 3) < 63 ? (kObs + A + 3) : 63;   // the grid rows go back only when a lane changed its grid
-  constexpr int kFull = A + 3;                                     // fully observed: at least these
+  constexpr int kState = A == 3 ? 1 : A + 1;                       // env_state: one 16-byte store with three agents, else a word each
+  constexpr int kLo = (kObs + kState + 2) < 63 ? (kObs + kState + 2) : 63;   // the grid rows go back only when a lane changed its grid
+  constexpr int kFull = kState + 2;                                // fully observed: at least these
   dyn_wait<A, 0, PRE>(cur);      // on every path, right after the barrier (see mg_kernel)
+#ifdef MG_PHASE_TIMERS
+  uint32_t ph_acc[kPhases] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t ph_k = __builtin_amdgcn_s_memtime();
+#endif
   for (; c < p.n_chunks; c += cstride) {
     const int64_t cn = c + cstride;
     const bool more = cn < p.n_chunks;          // wave-uniform
     if (more) dyn_load<A, PRE>(p, cn * kWave, lane, nxt);
-    dyn_chunk<A, V, FULL, PRE, DEC>(p, dist, lut, base, pidx, cpc, stage, gw, lane, c * kWave, cur, err);
+#ifdef MG_PHASE_TIMERS
+    { const uint64_t now = __builtin_amdgcn_s_memtime(); ph_acc[9] += (uint32_t)(now - ph_k); ph_k = now; }     // prefetch issue
+#endif
+    dyn_chunk<A, V, FULL, PRE, DEC>(p, dist, lut, base, pidx, cpc, stage, gw, lane, c * kWave, cur, err MG_PH_ARG);
+#ifdef MG_PHASE_TIMERS
+    ph_k = __builtin_amdgcn_s_memtime();
+#endif
     if (more) {
       if (FULL) dyn_wait<A, kFull, PRE>(nxt); else dyn_wait<A, kLo, PRE>(nxt);
       cur = nxt;
     }
+#ifdef MG_PHASE_TIMERS
+    { const uint64_t now = __builtin_amdgcn_s_memtime(); ph_acc[10] += (uint32_t)(now - ph_k); ph_k = now; ph_acc[11] += 1u; }   // counted wait; chunks
+#endif
   }
+#ifdef MG_PHASE_TIMERS
+  { const int wid = (int)(blockIdx.x * nw + wv);
+    if (lane == 0 && wid < kPhaseWaves) for (int i = 0; i < kPhases; ++i) g_phase[wid * kPhases + i] += ph_acc[i]; }
+#endif
   if (err) atomicOr(p.err, err);
 }
 
 // mg_export_grid: de-block the per-env grids into plain [n][W*H] byte arrays of public kind ids
-__global__ void export_grid_kernel(const uint8_t* grid, int GW, int cells, int64_t n_envs, uint8_t* out) {
+__global__ void export_grid_kernel(const uint8_t* grid, int GB, int cells, int64_t n_envs, uint8_t* out) {
   const int64_t total = n_envs * cells;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = i / cells;
     const int ci = (int)(i - n * cells);
-    out[i] = (uint8_t)kind_from_code(grid[((n >> 6) * GW * 4 + ci) * kWave + (n & 63)]);
+    out[i] = (uint8_t)kind_from_code(grid[(n >> 6) * (int64_t)GB * (kWave * 16) + grid_byte(ci, (int)(n & 63))]);
   }
 }

@@ -90,6 +90,7 @@ struct Params {
   uint32_t* err;
   // mutable-grid kernel only (mg_dyn.h)
   int32_t kind, GW;            // MG_KIND_*, grid dwords per env
+  int32_t inv_w20, GB;         // ceil(2^20 / W): cell index -> row by multiply and shift; GB = ceil(GW / 4) 16-byte row groups (mg_dyn.h)
   const uint32_t* base_grid;   // [GW] kind ids of the layout every reset starts from
   const uint32_t* grid0;       // mg_set_maps: [n_chunks][GW][64] per-env layouts every reset starts from (else null)
   const uint32_t* objdrop;     // int8x4 per (env, agent)
@@ -333,7 +334,9 @@ __device__ __forceinline__ void emit_obs(pd_t<A> pd, int a, uint32_t (&s)[ViewGe
   const int rx = -fy, ry = fx;
   // This lane's image occupies bytes [lane*ROWB, lane*ROWB+ROWB) of the wave chunk, which is not
   // dword aligned.  A lane owns the chunk dwords that START inside its byte range; the last of
-  // them is completed with the first bytes of the next lane's stream.
+  // them is completed with the first bytes of the next lane's stream.  (gfx950's LDS also takes unaligned 16-byte
+  // stores, which would save the shuffle and the byte alignment: measured in round 3, the static kernel went from
+  // 50.5 to 57.5 us and DoorKey-8x8 from 137.5 to 163 us with them.)
   const uint32_t nxt0 = __shfl_down(s[0], 1);
   s[NW - 1] |= (nxt0 & 255u) << 24;
   s[NW] = nxt0 >> 8;
@@ -346,9 +349,9 @@ __device__ __forceinline__ void emit_obs(pd_t<A> pd, int a, uint32_t (&s)[ViewGe
     const uint32_t v = __builtin_amdgcn_alignbyte(s[j + 1], s[j], h);
     if (j < NW - 1 || j < cnt) stage[d0 + j] = v;
   }
+  uint8_t* sb = reinterpret_cast<uint8_t*>(stage) + b0;
   // other agents: patch their cell (3 bytes) if it lies in the view and is visible; encoded
   // (10, id, (dir_other - dir_obs - 1) mod 4)  (Agent.encode :137-139, rotate_left :289-295)
-  uint8_t* sb = reinterpret_cast<uint8_t*>(stage) + b0;
 #pragma unroll
   for (int b = 0; b < A; ++b) {
     if (b == a) continue;
@@ -357,8 +360,8 @@ __device__ __forceinline__ void emit_obs(pd_t<A> pd, int a, uint32_t (&s)[ViewGe
     const int along = ox * fx + oy * fy, side = ox * rx + oy * ry;
     const int vy = V - 1 - along, vx = side + V / 2;
     if ((unsigned)vx < (unsigned)V && (unsigned)vy < (unsigned)V) {
-      if ((vm >> (vy * V + vx)) & 1u) {
-        uint8_t* q = sb + (vx * V + vy) * 3;
+      if ((vm >> ((uint32_t)__mul24(vy, V) + (uint32_t)vx & 63u)) & 1u) {      // (32-bit index arithmetic, not widened)
+        uint8_t* q = sb + ((uint32_t)__mul24(__mul24(vx, V) + vy, 3) & 255u);
         q[0] = (uint8_t)MG_T_AGENT;
         q[1] = (uint8_t)b;
         q[2] = (uint8_t)(((uint32_t)aw_d(o) - (uint32_t)d - 1u) & 3u);
@@ -370,8 +373,8 @@ __device__ __forceinline__ void emit_obs(pd_t<A> pd, int a, uint32_t (&s)[ViewGe
     const int along = ox * fx + oy * fy, side = ox * rx + oy * ry;
     const int vy = V - 1 - along, vx = side + V / 2;
     if ((unsigned)vx < (unsigned)V && (unsigned)vy < (unsigned)V) {
-      if ((vm >> (vy * V + vx)) & 1u) {
-        uint8_t* q = sb + (vx * V + vy) * 3;
+      if ((vm >> ((uint32_t)__mul24(vy, V) + (uint32_t)vx & 63u)) & 1u) {      // (32-bit index arithmetic, not widened)
+        uint8_t* q = sb + ((uint32_t)__mul24(__mul24(vx, V) + vy, 3) & 255u);
         q[0] = (uint8_t)MG_T_DOOR;
         q[1] = (uint8_t)((doorw >> 16) & 7u);
         q[2] = (uint8_t)((doorw >> 12) & 3u);
@@ -384,23 +387,41 @@ __device__ __forceinline__ void emit_obs(pd_t<A> pd, int a, uint32_t (&s)[ViewGe
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   constexpr int NV = 4 * ROWB;                // 16-byte vectors in the 64-image chunk
+  constexpr int NI = (NV + kWave - 1) / kWave; // ... per lane; only the last may fall past the chunk
   const uint4* src = reinterpret_cast<const uint4*>(stage);
   uint4* dst = reinterpret_cast<uint4*>(gchunk);
+  // all the LDS reads first, then the stores, and the (wave-uniform) choice of store flavour outside the loops: one LDS
+  // round trip per image chunk instead of one per vector
+  uint4 v[NI];
 #pragma unroll
-  for (int i = 0; i < (NV + kWave - 1) / kWave; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int idx = i * kWave + lane;
-#if MG_ABL == 1
-    if (idx < NV) { uint4 v = src[idx]; asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
-#else
-    if (idx < NV) store_vec16(dst + idx, src[idx], nt);
-#endif
+    v[i] = ((i + 1) * kWave <= NV || idx < NV) ? src[idx] : make_uint4(0u, 0u, 0u, 0u);
   }
+#if MG_ABL == 1
+#pragma unroll
+  for (int i = 0; i < NI; ++i) asm volatile("" :: "v"(v[i].x), "v"(v[i].y), "v"(v[i].z), "v"(v[i].w));
+#else
+  if (nt) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int idx = i * kWave + lane;
+      if ((i + 1) * kWave <= NV || idx < NV) store_vec16(dst + idx, v[i], true);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int idx = i * kWave + lane;
+      if ((i + 1) * kWave <= NV || idx < NV) store_vec16(dst + idx, v[i], false);
+    }
+  }
+#endif
   if (gchunk2) {                               // wave-uniform; only the fused rollout ever passes one
     uint4* dst2 = reinterpret_cast<uint4*>(gchunk2);
 #pragma unroll
-    for (int i = 0; i < (NV + kWave - 1) / kWave; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int idx = i * kWave + lane;
-      if (idx < NV) store_vec16(dst2 + idx, src[idx], false);
+      if ((i + 1) * kWave <= NV || idx < NV) store_vec16(dst2 + idx, v[i], false);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1067,13 +1088,13 @@ __global__ void sqrt_probe(int n, double* out) {
 // mg_set_maps: the caller's per-env layouts (device uint8[n_envs][H*W*3] cell triples) -> cell codes in the blocked layout of
 // the per-env grids, plus every env's own shaper goal (get_goal_position, v8_robust_ppo.py:159-169: first goal scanning
 // x-major, (13,13) if none) into aux word 0.  One thread per env: a one-off import, not a hot path.
-__global__ void import_maps_kernel(const uint8_t* cells, int W, int H, int GW, int A, int64_t n_envs, uint8_t* grid0, uint32_t* aux,
+__global__ void import_maps_kernel(const uint8_t* cells, int W, int H, int GB, int A, int64_t n_envs, uint8_t* grid0, uint32_t* aux,
                                    uint32_t* err) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= n_envs) return;
   const int ncell = W * H;
   const uint8_t* c = cells + n * ncell * 3;
-  uint8_t* g = grid0 + (n >> 6) * (int64_t)GW * 4 * kWave + (n & 63);
+  uint8_t* g = grid0 + (n >> 6) * (int64_t)GB * (kWave * 16);      // this env's chunk block; grid_byte() places (cell, lane)
   int n_free = 0;
   bool bad = false;
   for (int ci = 0; ci < ncell; ++ci) {
@@ -1086,7 +1107,7 @@ __global__ void import_maps_kernel(const uint8_t* cells, int W, int H, int GW, i
       case MG_T_DOOR: if (st > 2) { bad = true; k = K_WALL; } else k = code_from_kind(128 + col * 4 + st); break;
       default: bad = true; k = K_WALL; break;
     }
-    g[(int64_t)ci * kWave] = (uint8_t)k;
+    g[grid_byte(ci, (int)(n & 63))] = (uint8_t)k;
   }
   uint32_t goal = 13u | (13u << 6);
   bool found = false;
@@ -1471,6 +1492,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   p.obs_image = h->buf.obs_image; p.reward = h->buf.reward;
   p.env_reward = h->buf.env_reward; p.dir_done = h->buf.dir_done; p.env_state = h->buf.env_state; p.err = h->err;
   p.kind = c.env_kind; p.GW = h->GW; p.base_grid = h->base_grid;
+  p.inv_w20 = ((1 << 20) + c.width - 1) / c.width; p.GB = (h->GW + 3) / 4;
   p.grid0 = h->per_env_maps ? h->grid0 : nullptr;
   p.objdrop = reinterpret_cast<const uint32_t*>(objdrop);
   p.reset_gen = reinterpret_cast<const uint32_t*>(reset_gen);
@@ -1544,7 +1566,7 @@ int enable_dynamic(mg_handle* h, const std::vector<uint8_t>& kinds, int gx, int 
   if (!h->grid) {
     if (rc == MG_OK) rc = dalloc(h, &h->base_grid, (size_t)h->GW);
     if (rc == MG_OK) rc = dalloc(h, &h->carry, (size_t)h->stride * (h->cfg.n_agents > 4 ? 2 : 1));
-    if (rc == MG_OK) rc = dalloc(h, &h->grid, (size_t)h->n_chunks * h->GW * kWave);
+    if (rc == MG_OK) rc = dalloc(h, &h->grid, (size_t)h->n_chunks * ((h->GW + 3) / 4 * 4) * kWave);
     if (rc != MG_OK) return rc;
   }
   std::vector<uint32_t> base((size_t)h->GW, 0u);       // the layout as cell codes (mg_dyn.h), from public kind ids
@@ -1563,7 +1585,7 @@ int enable_dynamic(mg_handle* h, const std::vector<uint8_t>& kinds, int gx, int 
   h->dynamic = true; h->use_table = false; h->n_entries = 0;
   h->have_map = true;
   h->have_reset = false;          // positions and grids of the old layout mean nothing on the new one
-  h->buf.carry = h->carry; h->buf.grid = h->grid; h->buf.grid_words = h->GW; h->buf.mutable_grid = 1;
+  h->buf.carry = h->carry; h->buf.grid = h->grid; h->buf.grid_words = (h->GW + 3) / 4 * 4; h->buf.mutable_grid = 1;
   return MG_OK;
 }
 
@@ -1853,12 +1875,12 @@ int mg_set_maps(mg_handle* h, const uint8_t* cells) {
   if (rc != MG_OK) return rc;
   DeviceGuard g(h->device);
   if (!g.ok) return fail(MG_EHIP, "hipSetDevice failed");
-  if (!h->grid0) rc = dalloc(h, &h->grid0, (size_t)h->n_chunks * h->GW * kWave);
+  if (!h->grid0) rc = dalloc(h, &h->grid0, (size_t)h->n_chunks * ((h->GW + 3) / 4 * 4) * kWave);
   if (rc == MG_OK && !h->aux) rc = dalloc(h, &h->aux, (size_t)h->stride * 4);
   if (rc != MG_OK) return rc;
   h->buf.aux = h->aux;
   const unsigned blocks = (unsigned)((c.n_envs + 255) / 256);
-  hipLaunchKernelGGL(import_maps_kernel, dim3(blocks), dim3(256), 0, h->stream, cells, c.width, c.height, h->GW, c.n_agents, c.n_envs,
+  hipLaunchKernelGGL(import_maps_kernel, dim3(blocks), dim3(256), 0, h->stream, cells, c.width, c.height, (h->GW + 3) / 4, c.n_agents, c.n_envs,
                      reinterpret_cast<uint8_t*>(h->grid0), h->aux, h->err);
   HIP_TRY(hipGetLastError());
   h->free_cells.assign((size_t)c.width * c.height, 0);     // no fixed start cells on per-env layouts
@@ -1958,7 +1980,7 @@ int mg_export_grid(mg_handle* h, uint8_t* out) {
   const int cells = h->cfg.width * h->cfg.height;
   const int64_t total = h->cfg.n_envs * cells;
   const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65536);
-  hipLaunchKernelGGL(export_grid_kernel, dim3(blocks), dim3(256), 0, h->stream, reinterpret_cast<const uint8_t*>(h->grid), h->GW,
+  hipLaunchKernelGGL(export_grid_kernel, dim3(blocks), dim3(256), 0, h->stream, reinterpret_cast<const uint8_t*>(h->grid), (h->GW + 3) / 4,
                      cells, h->cfg.n_envs, out);
   HIP_TRY(hipGetLastError());
   return MG_OK;
@@ -2266,6 +2288,24 @@ int mg_debug_device_rewards(int device, int32_t max_steps, double* out) {
   if (e != hipSuccess) return fail(MG_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
   return MG_OK;
 }
+
+#ifdef MG_PHASE_TIMERS
+// timing-only builds: the phase counters of mg_dyn.h (sum over all waves, shader-clock cycles), optionally cleared afterwards
+int mg_debug_phase_counters(unsigned long long* out16, int reset) {
+  if (!out16) return fail(MG_EINVAL, "null argument");
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<unsigned int> w((size_t)kPhaseWaves * kPhases);
+  HIP_TRY(hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(g_phase), w.size() * sizeof(unsigned int)));
+  for (int i = 0; i < 16; ++i) out16[i] = 0;
+  for (int k = 0; k < kPhaseWaves; ++k)
+    for (int i = 0; i < kPhases; ++i) out16[i] += w[(size_t)k * kPhases + i];
+  if (reset) {
+    std::fill(w.begin(), w.end(), 0u);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), w.data(), w.size() * sizeof(unsigned int)));
+  }
+  return MG_OK;
+}
+#endif
 
 // Test hook (host only, no GPU): the mutable grids' cell code of a public kind id (MG_KIND_ID), the id it exports back
 // as, its table word (encode() triple | flags<<24) and the triple the arithmetic decode of the views extracts from the code

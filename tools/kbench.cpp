@@ -92,6 +92,9 @@ int main(int argc, char** argv) {
     if (a.sync(a.h) != MG_OK || hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "%s: warm-up failed: %s\n", argv[i], a.last_error()); return 3; }
     apis.push_back(a);
   }
+  typedef int (*phase_fn)(unsigned long long*, int);
+  for (auto& a : apis)        // timing-only builds with -DMG_PHASE_TIMERS: clear what the warm-up accumulated
+    if (phase_fn ph = (phase_fn)dlsym(a.dl, "mg_debug_phase_counters")) { unsigned long long tmp[16]; ph(tmp, 1); }
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int r = 0; r < rounds; ++r)
@@ -114,6 +117,20 @@ int main(int argc, char** argv) {
     printf("%-40s n=%lld  median %.2f us  min %.2f us  alg %.0f GB/s (%.1f%% of 8 TB/s, %.0f B/env-step)  %.3e agent-steps/s  err=%u\n",
            argv[5 + i], (long long)n, med, mn, env_bytes * n / med / 1e3, env_bytes * n / med / 1e3 / 80.0, env_bytes,
            (double)A * n / (med * 1e-6), err);
+    if (phase_fn ph = (phase_fn)dlsym(apis[i].dl, "mg_debug_phase_counters")) {
+      unsigned long long c[16];
+      if (ph(c, 0) == MG_OK) {
+        unsigned long long tot = 0;
+        for (int k = 0; k < 11; ++k) tot += c[k];
+        const double chunk_steps = (double)c[11];          // chunks the waves counted themselves
+        static const char* names[11] = {"grid rows -> LDS", "unpack, actions, order", "step_one_agent x A", "rewards, shaper",
+                                        "reset / auto-reset", "state + grid stores", "views", "staging + obs stores", "tail",
+                                        "prefetch issue", "counted wait for prefetch"};
+        printf("    phase timers (shader-clock cycles per chunk-step of one wave, stalls included; %% of the chunk; %.0f chunk-steps):\n", chunk_steps);
+        for (int k = 0; k < 11; ++k) printf("      %-26s %9.0f  %5.1f%%\n", names[k], c[k] / chunk_steps, 100.0 * c[k] / (double)tot);
+        printf("      %-26s %9.0f\n", "sum", tot / chunk_steps);
+      }
+    }
     if (getenv("MG_KBENCH_GEOMETRY")) {      // launch geometry of the handle (workgroup size, grid, LDS per workgroup)
       auto info = (decltype(&mg_get_launch_info))dlsym(apis[i].dl, "mg_get_launch_info");
       int32_t path = 0, bt = 0, gb = 0, lds = 0;
