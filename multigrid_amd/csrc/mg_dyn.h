@@ -458,7 +458,8 @@ static __device__ unsigned int g_phase[kPhaseWaves * kPhases];
 template <int A, int V, bool FULL, int PRE, bool DEC>
 __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, const uint32_t* lut, const uint32_t* base,
                                           const uint16_t* pidx, const uint16_t* cpc, uint32_t* stage, uint32_t* gw, int lane,
-                                          int64_t env0, const DynIn<A, PRE>& in, uint32_t& err_acc MG_PH_PARAM) {
+                                          int64_t env0, const DynIn<A, PRE>& in, DynIn<A, PRE>& nxt, int64_t env_next,
+                                          uint32_t& err_acc MG_PH_PARAM) {
   constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
   const int64_t n = env0 + lane;
   const bool active = n < p.n_envs;
@@ -824,6 +825,14 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   }
 
   MG_PH(5);      // state stores, grid rows -> HBM
+  // The next chunk's inputs are requested here, ahead of this chunk's burst of obs stores (at the top of the loop they
+  // queued behind the previous chunk's burst: round 3 phase timers, 6 % of a DoorKey chunk went into issuing them).
+  // env_next < 0: no next chunk (wave-uniform).  Fully observed kinds keep the request at the top of the loop: the
+  // number of stores emit_full issues is not a compile-time constant for the counted wait.
+  if constexpr (!FULL) {
+    if (env_next >= 0) dyn_load<A, PRE>(p, env_next, lane, nxt);
+    MG_PH(9);    // prefetch issue
+  }
   // ---- gen_obs (multigrid.py:1037-1067) --------------------------------------------------------
 #if MG_ABL != 2
   if (FULL) {
@@ -861,6 +870,10 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 template <int A, int V, bool FULL, int PRE, bool DEC>
 __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up to 8 waves per workgroup (dyn_geometry)
   constexpr int ROWB = ViewGeom<V>::ROWB;
+  // (The ~85 dwords of Params do not fit the 102 SGPRs next to the loop's own uniform values: the compiler spills ~350
+  //  of them to VGPR lanes and reads whole 16-dword kernarg tuples back, ~700 v_readlane per chunk.  Holding the eight
+  //  per-chunk pointers in vector registers instead removed a quarter of those and made DoorKey-8x8 5 % SLOWER
+  //  (138 -> 144 us, round 3), so the spills stay.)
   extern __shared__ __align__(16) uint8_t smem[];
   // LDS carve: [stage: nw x 64*ROWB B][grids: nw x (W+2)(H+2)*68 B][distance LUT: LW*LH f64][kind LUT: 256 u32]
   //            [base: GW u32][pidx: W*H u16][cpc: W*H u16]
@@ -897,15 +910,16 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up t
   uint32_t* stage = stage_all + wv * (stage_b / 4);
   uint32_t* gw = grids + (size_t)wv * pcells * kCellW;
   uint32_t err = 0;
-  // vector-memory operations a chunk issues after the next chunk's prefetch, all of them for at
-  // least one lane: obs stores, env_state, carry, dir_done (rewards in a step and dirty grid rows on top)
+  // vector-memory operations a chunk issues after the next chunk's prefetch, all of them for at least one lane.
+  // Partial views: the obs stores (the request is issued right before them, dyn_chunk).  Fully observed: the request is
+  // at the top of the loop, so env_state, carry, dir_done (rewards in a step, dirty grid rows and the images on top).
 #if MG_ABL == 0 || MG_ABL >= 3
   constexpr int kObs = A * ((4 * ROWB + kWave - 1) / kWave);
 #else
   constexpr int kObs = 0;
 #endif
   constexpr int kState = A == 3 ? 1 : A + 1;                       // env_state: one 16-byte store with three agents, else a word each
-  constexpr int kLo = (kObs + kState + 2) < 63 ? (kObs + kState + 2) : 63;   // the grid rows go back only when a lane changed its grid
+  constexpr int kLo = kObs < 63 ? kObs : 63;                       // partial views: the request sits right before the obs stores
   constexpr int kFull = kState + 2;                                // fully observed: at least these
   dyn_wait<A, 0, PRE>(cur);      // on every path, right after the barrier (see mg_kernel)
 #ifdef MG_PHASE_TIMERS
@@ -915,11 +929,11 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up t
   for (; c < p.n_chunks; c += cstride) {
     const int64_t cn = c + cstride;
     const bool more = cn < p.n_chunks;          // wave-uniform
-    if (more) dyn_load<A, PRE>(p, cn * kWave, lane, nxt);
+    if (FULL && more) dyn_load<A, PRE>(p, cn * kWave, lane, nxt);
 #ifdef MG_PHASE_TIMERS
     { const uint64_t now = __builtin_amdgcn_s_memtime(); ph_acc[9] += (uint32_t)(now - ph_k); ph_k = now; }     // prefetch issue
 #endif
-    dyn_chunk<A, V, FULL, PRE, DEC>(p, dist, lut, base, pidx, cpc, stage, gw, lane, c * kWave, cur, err MG_PH_ARG);
+    dyn_chunk<A, V, FULL, PRE, DEC>(p, dist, lut, base, pidx, cpc, stage, gw, lane, c * kWave, cur, nxt, more ? cn * kWave : -1, err MG_PH_ARG);
 #ifdef MG_PHASE_TIMERS
     ph_k = __builtin_amdgcn_s_memtime();
 #endif

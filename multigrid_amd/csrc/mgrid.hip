@@ -396,7 +396,7 @@ __device__ __forceinline__ void emit_obs(pd_t<A> pd, int a, uint32_t (&s)[ViewGe
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int idx = i * kWave + lane;
-    v[i] = ((i + 1) * kWave <= NV || idx < NV) ? src[idx] : make_uint4(0u, 0u, 0u, 0u);
+    v[i] = src[(i + 1) * kWave <= NV || idx < NV ? idx : NV - 1];      // (a clamped read, not a masked one: one ds_read_b128)
   }
 #if MG_ABL == 1
 #pragma unroll
