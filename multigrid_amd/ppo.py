@@ -25,6 +25,8 @@ from torch import nn
 from torch.distributions import Categorical
 import torch.nn.functional as F
 
+from . import fused_ops
+
 
 class AgentNet(nn.Module):
   """SimplePPOAgent (v8_robust_ppo.py:35-102), batch-first only."""
@@ -175,9 +177,9 @@ class StackedAgentNets(nn.Module):
     else:                                                                   # 'loop': one ordinary convolution per agent
       outs = []
       for a in range(A):
-        y = F.relu(F.conv2d(image[a].permute(0, 3, 1, 2).float(), self.conv1_w[a], self.conv1_b[a], padding=1))   # v8:75
-        y = F.relu(F.conv2d(y, self.conv2_w[a], self.conv2_b[a], padding=1))
-        outs.append(y.mean(dim=(2, 3)))
+        # bias + ReLU (+ the global average) are one pass over the activation each way (fused_ops.py, csrc/nn_ops.hip)
+        y = fused_ops.conv_bias_relu(image[a].permute(0, 3, 1, 2).float(), self.conv1_w[a], self.conv1_b[a])   # v8:75
+        outs.append(fused_ops.conv_bias_relu_mean(y, self.conv2_w[a], self.conv2_b[a]))
       feat = torch.stack(outs)
     idx = direction.long().unsqueeze(-1).expand(A, B, 8)
     emb = torch.gather(self.embed, 1, idx)                                  # direction_embed, per agent

@@ -28,6 +28,23 @@ def test_every_declared_symbol_is_exported_and_bound():
   assert sorted(lib.SYMBOLS) == names, 'ctypes binding out of sync with include/mgrid.h'
 
 
+def test_every_symbol_of_the_trainer_epilogue_header_is_exported_and_bound():
+  """include/mgrid_nn.h (the PPO trainer's fused convolution epilogues) against libmgnn.so and fused_ops.SYMBOLS; the
+  argument checks that run before any HIP call."""
+  from multigrid_amd import fused_ops
+  src = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'mgrid_nn.h')).read(), flags=re.S)
+  names = sorted(set(re.findall(r'\b(mgnn_[a-z_0-9]+)\s*\(', src)))
+  assert len(names) == 5 and sorted(fused_ops.SYMBOLS) == names
+  L = fused_ops.load()
+  for n in names:
+    assert hasattr(L, n), 'libmgnn.so does not export %s' % n
+  assert L.mgnn_partial_rows() == int(re.search(r'#define MGNN_PARTIAL_ROWS (\d+)', src).group(1))
+  for bad_c in (0, 3, 6, 24, 2048):      # not a power-of-two multiple of 4 up to 1024: refused before any launch
+    assert L.mgnn_bias_relu(None, None, 10, bad_c, None) == 1
+  assert L.mgnn_bias_relu_mean(None, None, None, 10, 0, 32, None) == 1
+  assert L.mgnn_bias_relu(None, None, 0, 32, None) == 0 and L.mgnn_bias_relu_mean(None, None, None, 0, 25, 64, None) == 0
+
+
 def test_struct_layouts_match_header(tmp_path):
   """sizeof/offsetof from a C compile of the header == the ctypes mirrors."""
   src = tmp_path / 'sz.c'
