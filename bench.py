@@ -66,7 +66,7 @@ def cpu_baseline(cells, seconds=12.0):
   return out
 
 
-TRAFFIC_FILES = ('r2_traffic.json', 'r1_traffic.json')   # newest first
+TRAFFIC_FILES = ('r3_traffic.json', 'r2_traffic.json', 'r1_traffic.json')   # newest first
 
 
 def kernel_source_hash():

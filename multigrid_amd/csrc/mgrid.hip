@@ -120,8 +120,10 @@ struct U4 { uint32_t x, y, z, w; };
 __device__ __forceinline__ U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    // one 32x32->64 multiply per product (v_mad_u64_u32) instead of a high and a low multiply, both quarter rate
+    const uint64_t m0 = (uint64_t)0xD2511F53u * c0, m1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t h0 = (uint32_t)(m0 >> 32), l0 = (uint32_t)m0;
+    const uint32_t h1 = (uint32_t)(m1 >> 32), l1 = (uint32_t)m1;
     const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
     c0 = n0; c1 = l1; c2 = n2; c3 = l0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -976,6 +978,11 @@ __global__ __launch_bounds__(kMaxBlock) void mg_rollout_kernel(const Params p) {
   // trajectory slot at a time, as one sweeping front of contiguous regions.  (One chunk per wave for all K steps, then
   // the next chunk, scatters the writes over K slots x all agents and reaches only ~4.5 TB/s.)  The state of a chunk
   // is six registers; the four sets rotate through set 0, so the big step body exists once.
+  // (Round 3: the rotation's struct selects keep the sets in 40 bytes of scratch per lane, and the s_waitcnt a scratch
+  //  load needs drains the chunk's obs stores each step.  Sets held in scalars with an unconditional four-way rotation
+  //  removed the scratch traffic and were SLOWER — 7.18 -> 7.86 us/step at 131072 x K32, 58.9 -> 60.2 at 1M x K16 — so
+  //  the form below stays.  What bounds the rollout is instruction issue: its one step body has 1722 VALU instructions
+  //  against 1485 per chunk in the step kernel, 259 of them v_readlane reloads of spilled SGPRs against 62.)
   struct St { pd_t<A> pd; uint32_t shw[A]; uint32_t st; };
   constexpr int NJ = 4;
   for (int64_t g0 = (int64_t)blockIdx.x * nw + wv; g0 < p.n_chunks; g0 += cstride * NJ) {
