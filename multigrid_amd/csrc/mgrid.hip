@@ -946,7 +946,11 @@ __global__ __launch_bounds__(kMaxBlock) void mg_kernel(const Params p) {
 // to slot k of the caller's trajectory buffers (write-once data: non-temporal stores), the last step's also to the
 // handle's own buffers.  What this removes from a step: the launch ramp and drain (~8 us per launch, the whole cost of
 // a step below ~100k envs) and the env_state / action traffic.
-template <int A, int V, bool TAB>
+// STD = the switches of the configuration the reference trains with — v8 shaping, auto-reset, not competitive, drawn
+// spawns, float64 rewards, opaque walls — are compile-time constants (launch() picks it when the handle matches): the
+// branches and the scalar registers that carry them go (round 3: 6.05 -> 5.69 us per step at 4096 envs, 7.00 -> 6.71 at
+// 131072; nothing at 1M envs, where the kernel waits on its stores).
+template <int A, int V, bool TAB, bool STD = false>
 __global__ __launch_bounds__(kMaxBlock) void mg_rollout_kernel(const Params p) {
   constexpr int ROWB = ViewGeom<V>::ROWB, ENTW = ViewGeom<V>::ENTW;
   extern __shared__ __align__(16) uint8_t smem[];
@@ -973,6 +977,9 @@ __global__ __launch_bounds__(kMaxBlock) void mg_rollout_kernel(const Params p) {
   const int64_t slot_obs = (int64_t)A * p.stride * ROWB, slot_rew = (int64_t)A * p.stride;
   const int64_t slot_dd = p.stride * p.dd_bytes, slot_act = p.stride * kSlotWords<A>;
   Params q = p;
+  if constexpr (STD) {
+    q.shaping = MG_SHAPING_V8; q.auto_reset = 1; q.competitive = 0; q.fixed_mode = MG_FIXED_OFF; q.reward_f32 = 0; q.see_through = 0;
+  }
   // A wave owns up to four chunks (one per "window" of cstride chunks, like the launch-resident step kernel) and takes
   // them through the K steps TOGETHER — step k of all its chunks, then step k + 1 — so that the whole chip writes one
   // trajectory slot at a time, as one sweeping front of contiguous regions.  (One chunk per wave for all K steps, then
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(kMaxBlock) void mg_rollout_kernel(const Params p) {
       const bool last = k == p.n_roll - 1;
       q.t = p.t + (uint64_t)k;
       q.obs_image = p.traj_obs + k * slot_obs;
-      q.reward = reinterpret_cast<double*>(reinterpret_cast<char*>(p.traj_reward) + k * slot_rew * (p.reward_f32 ? 4 : 8));
+      q.reward = reinterpret_cast<double*>(reinterpret_cast<char*>(p.traj_reward) + k * slot_rew * (!STD && p.reward_f32 ? 4 : 8));
       q.dir_done = p.traj_dd + k * slot_dd;
       q.actions_out = p.traj_actions ? p.traj_actions + k * slot_act : nullptr;
       q.actions = p.actions ? p.actions + k * slot_act : nullptr;
@@ -1144,13 +1151,14 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 typedef void (*kernel_fn)(const Params);
 
 // [0] general / [1] FAST instantiation of the generic-path and table-path kernels
-// roll[0] / roll[1]: the fused rollout on the generic / table path
-struct Variant { int A, V; kernel_fn generic[2], table[2]; int entw; kernel_fn roll[2]; };
+// roll[0] / roll[1]: the fused rollout on the generic / table path; roll_std: the same with the standard configuration's switches folded
+struct Variant { int A, V; kernel_fn generic[2], table[2]; int entw; kernel_fn roll[2], roll_std[2]; };
 #define MG_VARIANT_TAB(A, V) {A, V, {mg_kernel<A, V, false, false>, mg_kernel<A, V, false, true>}, \
                               {mg_kernel<A, V, true, false>, mg_kernel<A, V, true, true>}, ViewGeom<V>::ENTW, \
-                              {mg_rollout_kernel<A, V, false>, mg_rollout_kernel<A, V, true>}}
+                              {mg_rollout_kernel<A, V, false>, mg_rollout_kernel<A, V, true>}, \
+                              {mg_rollout_kernel<A, V, false, true>, mg_rollout_kernel<A, V, true, true>}}
 #define MG_VARIANT_GEN(A, V) {A, V, {mg_kernel<A, V, false, false>, mg_kernel<A, V, false, true>}, {nullptr, nullptr}, 0, \
-                              {mg_rollout_kernel<A, V, false>, nullptr}}
+                              {mg_rollout_kernel<A, V, false>, nullptr}, {mg_rollout_kernel<A, V, false, true>, nullptr}}
 // MG_MIN_BUILD (tools/gpu.sh build ... -DMG_MIN_BUILD): only what tools/kbench times — quick A/B builds, never the product
 const Variant kVariants[] = {
 #ifdef MG_MIN_BUILD
@@ -1541,7 +1549,9 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
       const int per_cu = std::max(1, std::min((int)((size_t)kLdsLimit / lds), 32 / nw));
       grid = (unsigned)std::min<int64_t>(grid, (int64_t)h->n_cu * per_cu);
     }
-    hipLaunchKernelGGL(h->var->roll[rt ? 1 : 0], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
+    const bool std_cfg = p.shaping == MG_SHAPING_V8 && p.auto_reset && !p.competitive && h->fixed_mode == MG_FIXED_OFF &&
+                         !p.reward_f32 && !c.see_through_walls && !debug_env("MG_DEBUG_ROLL_GENERAL");
+    hipLaunchKernelGGL((std_cfg ? h->var->roll_std : h->var->roll)[rt ? 1 : 0], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
     HIP_TRY(hipGetLastError());
     return launch_ep_stats(h, op, mask, n_roll, roll);
   }
@@ -1694,6 +1704,7 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   if (e != hipSuccess) { delete h; return fail(MG_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
   for (kernel_fn fn : {var ? var->generic[0] : nullptr, var ? var->generic[1] : nullptr, var ? var->table[0] : nullptr,
                        var ? var->table[1] : nullptr, var ? var->roll[0] : nullptr, var ? var->roll[1] : nullptr,
+                       var ? var->roll_std[0] : nullptr, var ? var->roll_std[1] : nullptr,
                        dvar ? dvar->fn[0] : nullptr, dvar ? dvar->fn[1] : nullptr}) {
     if (!fn) continue;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);

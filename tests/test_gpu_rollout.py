@@ -201,3 +201,35 @@ def test_rollout_on_mutable_grid_handles(playground_cells, env_id, kw):
   assert torch.equal(env.grid_kinds(), twin.grid_kinds()) and env.step_index == twin.step_index == 3 * K
   assert env.check_errors() == 0 and twin.check_errors() == 0
   env.close(); twin.close()
+
+
+@pytest.mark.parametrize('path', ['generic', 'table'])
+def test_standard_config_instantiation_equals_the_general_one(cluttered_cells, monkeypatch, path):
+  """The reference's training configuration (v8 shaping, auto-reset, three agents, drawn spawns, f64 rewards) runs a rollout
+  instantiation with those switches folded at compile time; MG_DEBUG_ROLL_GENERAL forces the general one.  Same trajectory,
+  same final state, bit for bit, across an auto-reset — and both against the oracle."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  monkeypatch.setenv('MG_DEBUG_ROLL_PATH', {'generic': '1', 'table': '2'}[path])
+  kp = 'table' if path == 'table' else 'auto'
+  n, K = 2500, 45
+  out = []
+  for general in (False, True):
+    if general:
+      monkeypatch.setenv('MG_DEBUG_ROLL_GENERAL', '1')
+    env = BatchedMultiGrid(cluttered_cells, n_envs=n, seed=21, max_steps=30, kernel_path=kp)
+    env.reset()
+    traj = env.rollout_random(K)
+    # (keys with a leading underscore are the raw padded buffers: their padding slots hold whatever the allocator left)
+    out.append({k: v.clone() for k, v in traj.items() if torch.is_tensor(v) and not k.startswith('_')} | {'state': env.agent_state.clone()})
+    assert env.check_errors() == 0
+    env.close()
+  assert {'image', 'reward', 'done', 'state'} <= set(out[0])
+  for k in out[0]:
+    assert torch.equal(out[0][k], out[1][k]), k
+  orc = c_oracle.OracleBatch(cluttered_cells, n, max_steps=30, shaping=1, auto_reset=1, seed=21)
+  orc.reset()
+  img, rew = out[0]['image'].cpu().numpy().reshape(K, 3, n, -1), out[0]['reward'].cpu().numpy()
+  for k in range(K):
+    orc.step(None)
+    assert np.array_equal(img[k], orc.obs_image[:, :n]) and np.array_equal(rew[k].view(np.int64), orc.reward[:, :n].view(np.int64)), k
