@@ -359,10 +359,10 @@ int mg_step_noalloc(const mg_config* cfg, int device, void* hip_stream, uint64_t
  * Afterwards the handle is exactly where n_steps calls of mg_step_random would have left it: env_state, step index, and
  * its own obs_image / reward / dir_done buffers hold the last step.  Handles without env_reward output only (MG_EUNSUPPORTED
  * otherwise); auto-reset and shaping as configured.  Mutable-grid handles (DoorKey, Meetup, drawn layouts, layouts with objects,
- * mg_set_maps) take the same call with the same result but run it as n_steps launches of their step kernel, each writing into its
- * slot — there is no fused kernel for them, and the last step's outputs are written to the handle's own buffers and copied into
- * the last slot, one extra full-size obs / reward / dir_done copy per call; fully observed kinds: obs_image is uint8
- * [n_steps][env_stride][W*H*3] (mg_buffers.obs_full). */
+ * mg_set_maps) take the same call with the same result and, since round 3, their own fused kernel: a wavefront copies its 64
+ * envs' grids into LDS once, takes them through the n_steps steps there (layout generation at auto-resets, pickups, doors), and
+ * writes grids / env_state / carry back once; fully observed kinds: obs_image is uint8 [n_steps][env_stride][W*H*3]
+ * (mg_buffers.obs_full). */
 typedef struct mg_rollout_out {
   uint8_t* obs_image;
   double*  reward;

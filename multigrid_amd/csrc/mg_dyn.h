@@ -379,15 +379,19 @@ __device__ __forceinline__ uint32_t meetup_dist(const Params& p, pd_t<A> pd, con
 // cell-major, so the wave gathers the 64 images straight into output order — lane l produces the
 // 16-byte vectors l, l+64, ... of the chunk's 64*W*H*3 contiguous bytes and every store instruction
 // writes 1 KB of contiguous bytes.  The agents are marked into the LDS grid for the duration (kinds
-// agent_mark(4*id + dir)); the next chunk's copy-in overwrites every interior cell, so they never leak.
-template <int A>
+// agent_mark(4*id + dir)); the next chunk's copy-in overwrites every interior cell, so they never leak — except in the
+// fused rollout, whose grids stay in LDS from step to step: RESTORE puts back what the marks covered.
+template <int A, bool RESTORE = false>
 __device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uint8_t* gwave, const uint32_t* lut,
-                                          const uint16_t* cpc, pd_t<A> pd, int lane, uint8_t* gchunk) {
+                                          const uint16_t* cpc, pd_t<A> pd, int lane, uint8_t* gchunk, uint8_t* gchunk2 = nullptr) {
   const int cells = p.W * p.H, FB = cells * 3;
+  uint32_t under[A];
 #pragma unroll
   for (int b = 0; b < A; ++b) {
     const uint32_t o = pd_get(pd, b);
-    g_set(g, g_off(p, aw_x(o), aw_y(o)), agent_mark(4u * (uint32_t)b + (uint32_t)aw_d(o)));
+    const int off = g_off(p, aw_x(o), aw_y(o));
+    if (RESTORE) under[b] = g_get(g, off);
+    g_set(g, off, agent_mark(4u * (uint32_t)b + (uint32_t)aw_d(o)));
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -396,6 +400,7 @@ __device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uin
   // image span exactly six consecutive cells (3*c0 + m .. 3*c0 + m + 15, m = r0 % 3), the last of
   // which may belong to the next image
   uint4* dst = reinterpret_cast<uint4*>(gchunk);
+  uint4* dst2 = reinterpret_cast<uint4*>(gchunk2);   // wave-uniform; only the fused rollout's last step passes one
   const int nv = 4 * FB;                        // 16-byte vectors in the 64-image chunk
   int e = 0, r0 = 16 * lane;                    // image index within the chunk and byte offset within it
   constexpr int UF = 2;                         // vectors per lane in flight (the dependent LDS reads of each overlap)
@@ -428,12 +433,25 @@ __device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uin
       v.y = __builtin_amdgcn_alignbyte(s2, s1, m[u]);
       v.z = __builtin_amdgcn_alignbyte(s3, s2, m[u]);
       v.w = __builtin_amdgcn_alignbyte(s4, s3, m[u]);
-      if (q + u * kWave < nv) store_vec16(dst + q + u * kWave, v, p.nt_obs != 0);
+      if (q + u * kWave < nv) {
+        store_vec16(dst + q + u * kWave, v, p.nt_obs != 0);
+        if (dst2) store_vec16(dst2 + q + u * kWave, v, false);
+      }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (RESTORE) {                                 // (agents never share a cell, so the order does not matter)
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+      const uint32_t o = pd_get(pd, b);
+      g_set(g, g_off(p, aw_x(o), aw_y(o)), under[b]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 }
 
 // -DMG_PHASE_TIMERS (timing-only builds, tools/gpu.sh build ... ; never the product): where a wave's time goes.  The shader
@@ -454,23 +472,22 @@ static __device__ unsigned int g_phase[kPhaseWaves * kPhases];
 #define MG_PH(i) do {} while (0)
 #endif
 
-// One chunk (64 envs) of one step()/reset() on mutable grids.
-template <int A, int V, bool FULL, int PRE, bool DEC>
-__device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, const uint32_t* lut, const uint32_t* base,
-                                          const uint16_t* pidx, const uint16_t* cpc, uint32_t* stage, uint32_t* gw, int lane,
-                                          int64_t env0, const DynIn<A, PRE>& in, DynIn<A, PRE>& nxt, int64_t env_next,
-                                          uint32_t& err_acc MG_PH_PARAM) {
-  constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
-  const int64_t n = env0 + lane;
-  const bool active = n < p.n_envs;
-  const uint32_t gid = (uint32_t)(p.gid_base + (uint64_t)n);
-  const uint32_t all = (1u << A) - 1u;
-  const int cells = p.W * p.H;
-  MG_PH_BEGIN();
+// Fused K-step rollout on mutable grids (mg_dyn_rollout_kernel): what a chunk keeps in registers from one step of the
+// launch to the next — its 64 grids stay in the wave's LDS meanwhile — and what tells a step where it stands.
+template <int A> struct DynSt {
+  pd_t<A> pd; uint32_t shw[A]; uint32_t st; carry_t<A> carry; uint32_t goal[3]; uint32_t past; bool dirty;
+};
+struct DynRoll {
+  bool last;                 // the launch's last step: grids and state go back to HBM, and the outputs also go to the handle's own buffers
+  uint8_t* obs2; double* reward2; uint8_t* dd2;     // those buffers (null unless last)
+};
 
-  // ---- this wave's 64 grids: HBM rows -> padded LDS grid.  Dword d = lane + 64k of the chunk holds
-  //      lanes 4*(d%16)..+3 of cell d/16; it goes to LDS dword pidx[cell]*17 + d%16. ---------------
-  uint4* const ghbm = reinterpret_cast<uint4*>(p.grid) + (env0 >> 6) * (int64_t)p.GB * kWave;   // this chunk's grid block
+// The start of a chunk: this wave's 64 grids, HBM rows -> padded LDS grid (dword d = lane + 64k of the chunk holds lanes
+// 4*(d%16)..+3 of cell d/16; it goes to LDS dword pidx[cell]*17 + d%16), and the chunk's state unpacked from its input words.
+template <int A, int PRE>
+__device__ __forceinline__ void dyn_begin(const Params& p, uint32_t* gw, int lane, int64_t env0, const DynIn<A, PRE>& in, DynSt<A>& S) {
+  const int cells = p.W * p.H;
+  const uint4* const ghbm = reinterpret_cast<const uint4*>(p.grid) + (env0 >> 6) * (int64_t)p.GB * kWave;   // this chunk's grid block
   const int l4 = lane & 15, c4 = lane >> 4;
   // LDS dword of cell ci = y*W + x for this lane's four envs: ((y+1)(W+2) + x+1)*17 + l4 = (ci + 2y + W+3)*17 + l4, with
   // y = ci / W as one 24-bit multiply and a shift (inv_w20 = ceil(2^20 / W): exact for ci < 2^20 / W, i.e. any grid here).
@@ -506,26 +523,59 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  MG_PH(0);      // grid rows -> LDS
-  uint8_t* const g = reinterpret_cast<uint8_t*>(gw) + lane;
-  bool dirty = false;            // this env's grid changed: the wave's rows go back to HBM only if some lane's did
-  auto gs = [&](int off, uint32_t k) { g_set(g, off, k); dirty = true; };
-
-  pd_t<A> pd = pd_t<A>{};
-  uint32_t shw[A];
-  uint32_t actw = 0, err = 0;
+  S.pd = pd_t<A>{};
 #pragma unroll
   for (int a = 0; a < A; ++a) {
     const uint32_t w = in.st[a];
     const uint32_t cx = min(w & 63u, (uint32_t)(p.W - 1)), cy = min((w >> 6) & 63u, (uint32_t)(p.H - 1));
-    pd = pd_set(pd, a, cx | (cy << 6) | (w & 0x3000u));
-    shw[a] = w & ~AW_POSDIR;
+    S.pd = pd_set(S.pd, a, cx | (cy << 6) | (w & 0x3000u));
+    S.shw[a] = w & ~AW_POSDIR;
   }
-  uint32_t st = in.st[A];
-  carry_t<A> carry = carry_to_codes(in.carry);                // HBM keeps public kind ids (mg_buffers.carry)
-  if constexpr (A > 4) carry |= (uint64_t)carry_to_codes(in.carry2) << 32;
-  uint32_t goal[3] = {in.aux[0], in.aux[1], in.aux[2]};       // MEETUP: goal_pos[2k] | goal_pos[2k+1] << 16, each x | y<<6
-  uint32_t past = in.aux[3];                                  // MEETUP: past_goal_dist, one byte per agent
+  S.st = in.st[A];
+  S.carry = carry_to_codes(in.carry);                         // HBM keeps public kind ids (mg_buffers.carry)
+  if constexpr (A > 4) S.carry |= (uint64_t)carry_to_codes(in.carry2) << 32;
+  S.goal[0] = in.aux[0]; S.goal[1] = in.aux[1]; S.goal[2] = in.aux[2];
+  S.past = in.aux[3];
+  S.dirty = false;
+}
+
+// One chunk (64 envs) of one step()/reset() on mutable grids.  ROLL = a step of the fused rollout: free-running, no injection,
+// no prefetch of a next chunk; state in S between the steps.
+template <int A, int V, bool FULL, int PRE, bool DEC, bool ROLL = false>
+__device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, const uint32_t* lut, const uint32_t* base,
+                                          const uint16_t* pidx, const uint16_t* cpc, uint32_t* stage, uint32_t* gw, int lane,
+                                          int64_t env0, const DynIn<A, PRE>& in, DynIn<A, PRE>& nxt, int64_t env_next,
+                                          uint32_t& err_acc MG_PH_PARAM, DynSt<A>* S = nullptr, const DynRoll* R = nullptr) {
+  constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
+  const bool last = !ROLL || R->last;      // compile-time true outside the rollout
+  const int64_t n = env0 + lane;
+  const bool active = n < p.n_envs;
+  const uint32_t gid = (uint32_t)(p.gid_base + (uint64_t)n);
+  const uint32_t all = (1u << A) - 1u;
+  const int cells = p.W * p.H;
+  MG_PH_BEGIN();
+
+  uint4* const ghbm = reinterpret_cast<uint4*>(p.grid) + (env0 >> 6) * (int64_t)p.GB * kWave;   // this chunk's grid block
+  const int l4 = lane & 15, c4 = lane >> 4;
+  const int ldw0 = __mul24(p.W + 3, kCellW) + l4;              // see dyn_begin
+  auto lds_dword = [&](int ci) { return __mul24(ci + 2 * (int)(__umul24((uint32_t)ci, (uint32_t)p.inv_w20) >> 20), kCellW) + ldw0; };
+  DynSt<A> S0;
+  if constexpr (!ROLL) dyn_begin<A, PRE>(p, gw, lane, env0, in, S0);
+  const DynSt<A>& Sin = ROLL ? *S : S0;
+  MG_PH(0);      // grid rows -> LDS
+  uint8_t* const g = reinterpret_cast<uint8_t*>(gw) + lane;
+  bool dirty = Sin.dirty;        // this env's grid changed: the wave's rows go back to HBM only if some lane's did
+  auto gs = [&](int off, uint32_t k) { g_set(g, off, k); dirty = true; };
+
+  pd_t<A> pd = Sin.pd;
+  uint32_t shw[A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) shw[a] = Sin.shw[a];
+  uint32_t actw = 0, err = 0;
+  uint32_t st = Sin.st;
+  carry_t<A> carry = Sin.carry;
+  uint32_t goal[3] = {Sin.goal[0], Sin.goal[1], Sin.goal[2]};   // MEETUP: goal_pos[2k] | goal_pos[2k+1] << 16, each x | y<<6
+  uint32_t past = Sin.past;                                     // MEETUP: past_goal_dist, one byte per agent
   // agents (re)spawn at x < spawn_w: the DoorKey split (doorkey.py:77-78), the whole grid otherwise
   int spawn_w = p.kind != MG_KIND_DOORKEY ? p.W : (int)min((st >> 24) & 63u, (uint32_t)p.W);
   // DoorKey also keeps its door's row (doorkey.py:58-61; the low five bits, split over the word's free bits 21..23 and
@@ -540,8 +590,13 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     if (MG_ABL != 3 && (p.random_actions || (A > 1 && !p.order))) blk = step_block(p, gid, P_ORDER);
     if (p.random_actions) actw = draw_actions<A>(p, n, gid, active, blk);
     else {
+      uint32_t a0 = in.act, a1 = in.act2;
+      if constexpr (ROLL) {                                   // this step's slot of the caller's action ring (p.actions points at it)
+        a0 = p.actions[n * kSlotWords<A>];
+        if (A > 4) a1 = p.actions[n * kSlotWords<A> + 1];
+      }
 #pragma unroll
-      for (int a = 0; a < A; ++a) actw |= min(((a < 4 ? in.act >> (8 * a) : in.act2 >> (8 * (a - 4)))) & 255u, 7u) << (3 * a);
+      for (int a = 0; a < A; ++a) actw |= min(((a < 4 ? a0 >> (8 * a) : a1 >> (8 * (a - 4)))) & 255u, 7u) << (3 * a);
     }
     uint32_t step = (st & 0xFFFFu) + 1u;                                        // multigrid.py:968
     uint32_t dbits = (st >> 16) & all;
@@ -655,6 +710,9 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
         const int64_t i = (int64_t)a * p.stride + n;
         if (p.reward_f32) reinterpret_cast<float*>(p.reward)[i] = (float)out_rew[a]; else p.reward[i] = out_rew[a];
         if (p.env_reward) p.env_reward[i] = rew[a];
+        if (ROLL && R->reward2) {
+          if (p.reward_f32) reinterpret_cast<float*>(R->reward2)[i] = (float)out_rew[a]; else R->reward2[i] = out_rew[a];
+        }
       }
     }
   }
@@ -771,28 +829,34 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 
   MG_PH(4);      // reset / auto-reset
   if (active) {
-    if constexpr (A == 3) {          // the four words of an env are one aligned 16-byte vector
-      reinterpret_cast<uint4*>(p.env_state)[n] = make_uint4(shw[0] | pd_get(pd, 0), shw[1] | pd_get(pd, 1), shw[2] | pd_get(pd, 2), st);
-    } else {
+    if (last) {
+      if constexpr (A == 3) {          // the four words of an env are one aligned 16-byte vector
+        reinterpret_cast<uint4*>(p.env_state)[n] = make_uint4(shw[0] | pd_get(pd, 0), shw[1] | pd_get(pd, 1), shw[2] | pd_get(pd, 2), st);
+      } else {
 #pragma unroll
-      for (int a = 0; a < A; ++a) p.env_state[n * (A + 1) + a] = shw[a] | pd_get(pd, a);
-      p.env_state[n * (A + 1) + A] = st;
+        for (int a = 0; a < A; ++a) p.env_state[n * (A + 1) + a] = shw[a] | pd_get(pd, a);
+        p.env_state[n * (A + 1) + A] = st;
+      }
+      p.carry[n * kSlotWords<A>] = carry_to_kinds((uint32_t)carry);
+      if constexpr (A > 4) p.carry[n * kSlotWords<A> + 1] = carry_to_kinds((uint32_t)(carry >> 32));
+      if (p.aux) reinterpret_cast<uint4*>(p.aux)[n] = make_uint4(goal[0], goal[1], goal[2], past);
     }
-    p.carry[n * kSlotWords<A>] = carry_to_kinds((uint32_t)carry);
-    if constexpr (A > 4) p.carry[n * kSlotWords<A> + 1] = carry_to_kinds((uint32_t)(carry >> 32));
-    if (p.aux) reinterpret_cast<uint4*>(p.aux)[n] = make_uint4(goal[0], goal[1], goal[2], past);
     uint64_t dd = (uint64_t)done_flag << (8 * A);
 #pragma unroll
     for (int a = 0; a < A; ++a) dd |= (uint64_t)aw_d(pd_get(pd, a)) << (8 * a);
     if (A + 1 <= 4) reinterpret_cast<uint32_t*>(p.dir_done)[n] = (uint32_t)dd;
     else reinterpret_cast<uint64_t*>(p.dir_done)[n] = dd;
+    if (ROLL && R->dd2) {
+      if (A + 1 <= 4) reinterpret_cast<uint32_t*>(R->dd2)[n] = (uint32_t)dd;
+      else reinterpret_cast<uint64_t*>(R->dd2)[n] = dd;
+    }
     err_acc |= err;
   }
   // ---- grids: LDS -> HBM rows (the reverse of the copy above; padding lanes' bytes are unused) ---
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (__builtin_amdgcn_ballot_w64(dirty) != 0ull) {          // wave-uniform
+  if (last && __builtin_amdgcn_ballot_w64(dirty) != 0ull) {          // wave-uniform
     if (p.GW <= PRE) {
       // the mirror of the copy-in, unrolled the same way: the same (kept or recomputed) addresses, every LDS read of
       // the grid in flight before the first store
@@ -829,14 +893,15 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   // queued behind the previous chunk's burst: round 3 phase timers, 6 % of a DoorKey chunk went into issuing them).
   // env_next < 0: no next chunk (wave-uniform).  Fully observed kinds keep the request at the top of the loop: the
   // number of stores emit_full issues is not a compile-time constant for the counted wait.
-  if constexpr (!FULL) {
+  if constexpr (!FULL && !ROLL) {
     if (env_next >= 0) dyn_load<A, PRE>(p, env_next, lane, nxt);
     MG_PH(9);    // prefetch issue
   }
   // ---- gen_obs (multigrid.py:1037-1067) --------------------------------------------------------
 #if MG_ABL != 2
   if (FULL) {
-    emit_full<A>(p, g, reinterpret_cast<const uint8_t*>(gw), lut, cpc, pd, lane, p.obs_full + env0 * (int64_t)(p.W * p.H * 3));
+    emit_full<A, ROLL>(p, g, reinterpret_cast<const uint8_t*>(gw), lut, cpc, pd, lane, p.obs_full + env0 * (int64_t)(p.W * p.H * 3),
+                 (ROLL && R->obs2) ? R->obs2 + env0 * (int64_t)(p.W * p.H * 3) : nullptr);
   } else {
     // DEC: the one door whose state the cell code cannot show (DoorKey's, at (split_idx, door_idx) for the whole
     // episode) is read back once per step; gone (walked through while open: move_agent overwrites it) or open -> no overlay
@@ -859,12 +924,18 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 #endif
       MG_PH(6);  // views
       emit_obs<A, V, DEC>(pd, a, s, vm, stage, lane, p.obs_image + ((int64_t)a * p.stride + env0) * ROWB, ((p.nt_obs >> a) & 1) != 0,
-                          nullptr, doorw);
+                          (ROLL && R->obs2) ? R->obs2 + ((int64_t)a * p.stride + env0) * ROWB : nullptr, doorw);
       MG_PH(7);  // staging + obs stores
     }
   }
 #endif
   MG_PH(8);
+  if constexpr (ROLL) {
+    S->pd = pd; S->st = st; S->carry = carry; S->past = past; S->dirty = dirty;
+#pragma unroll
+    for (int a = 0; a < A; ++a) S->shw[a] = shw[a];
+    S->goal[0] = goal[0]; S->goal[1] = goal[1]; S->goal[2] = goal[2];
+  }
 }
 
 template <int A, int V, bool FULL, int PRE, bool DEC>
@@ -949,6 +1020,78 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up t
   { const int wid = (int)(blockIdx.x * nw + wv);
     if (lane == 0 && wid < kPhaseWaves) for (int i = 0; i < kPhases; ++i) g_phase[wid * kPhases + i] += ph_acc[i]; }
 #endif
+  if (err) atomicOr(p.err, err);
+}
+
+#ifndef MG_DYN_ROLL_FULL_WAVES
+#define MG_DYN_ROLL_FULL_WAVES 3
+#endif
+// Fused K-step rollout on mutable grids (mg_rollout / mg_rollout_random on DoorKey, Meetup, drawn layouts, per-env maps):
+// p.n_roll consecutive free-running steps in ONE launch — exactly what p.n_roll launches of mg_dyn_kernel compute.  A wave
+// takes a chunk through all K steps before its next chunk: the 64 grids are copied into the wave's LDS once and written
+// back once (if any step changed them), env_state / carry / aux are read and written once, and step k's obs / rewards /
+// dir-done / actions go to slot k of the caller's trajectory buffers (the last step's also to the handle's own buffers, so
+// that the handle ends where K single calls would leave it).  What this removes from a step: the launch ramp and drain
+// (all of a step's cost at a few thousand envs), the grid and state traffic, and the per-chunk prologue.
+template <int A, int V, bool FULL, int PRE, bool DEC>
+__global__ __launch_bounds__(512, FULL ? MG_DYN_ROLL_FULL_WAVES : 1) void mg_dyn_rollout_kernel(const Params p) {   // fully observed: three waves per SIMD, like their step kernels
+  constexpr int ROWB = ViewGeom<V>::ROWB;
+  extern __shared__ __align__(16) uint8_t smem[];
+  // the LDS carve of mg_dyn_kernel
+  const int nw = blockDim.x >> 6;
+  const int pcells = (p.W + 2) * (p.H + 2), cells = p.W * p.H;
+  uint32_t* stage_all = reinterpret_cast<uint32_t*>(smem);
+  const int stage_b = FULL ? 0 : kWave * ROWB;
+  uint32_t* grids = reinterpret_cast<uint32_t*>(smem + (size_t)nw * stage_b);
+  double* dist = reinterpret_cast<double*>(grids + (size_t)nw * pcells * kCellW + ((nw * pcells * kCellW) & 1));
+  uint32_t* lut = reinterpret_cast<uint32_t*>(dist + p.LW * p.LH);
+  uint32_t* base = lut + 256;
+  uint16_t* pidx = reinterpret_cast<uint16_t*>(base + p.GW);
+  uint16_t* cpc = pidx + cells;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
+  for (int i = tid; i < 256; i += blockDim.x) lut[i] = kind_word((uint32_t)i);
+  for (int i = tid; i < p.GW; i += blockDim.x) base[i] = p.base_grid[i];
+  for (int i = tid; i < p.LW * p.LH; i += blockDim.x) dist[i] = p.dist_lut[i];
+  for (int i = tid; i < cells; i += blockDim.x) {
+    pidx[i] = (uint16_t)((i / p.W + 1) * (p.W + 2) + (i % p.W) + 1);
+    cpc[i] = (uint16_t)((i % p.H + 1) * (p.W + 2) + (i / p.H) + 1);
+  }
+  for (int i = tid; i < nw * pcells * kCellW; i += blockDim.x) grids[i] = K_WALL * 0x01010101u;
+  __syncthreads();
+
+  uint32_t* stage = stage_all + wv * (stage_b / 4);
+  uint32_t* gw = grids + (size_t)wv * pcells * kCellW;
+  uint32_t err = 0;
+  const int64_t cstride = (int64_t)gridDim.x * nw;
+  const int64_t slot_obs = FULL ? p.stride * (int64_t)(cells * 3) : (int64_t)A * p.stride * ROWB;
+  const int64_t slot_rew = (int64_t)A * p.stride * (p.reward_f32 ? 4 : 8);
+  const int64_t slot_dd = p.stride * p.dd_bytes, slot_act = p.stride * kSlotWords<A>;
+  Params q = p;
+  for (int64_t c = (int64_t)blockIdx.x * nw + wv; c < p.n_chunks; c += cstride) {
+    DynIn<A, PRE> cur = {};
+    dyn_load<A, PRE>(p, c * kWave, lane, cur);
+    dyn_wait<A, 0, PRE>(cur);            // once per K steps: nothing is in flight across code here
+    DynSt<A> S;
+    dyn_begin<A, PRE>(p, gw, lane, c * kWave, cur, S);
+    DynRoll R;
+#pragma unroll 1
+    for (int k = 0; k < p.n_roll; ++k) {
+      R.last = k == p.n_roll - 1;
+      R.obs2 = R.last ? (FULL ? p.obs_full : p.obs_image) : nullptr;
+      R.reward2 = R.last ? p.reward : nullptr;
+      R.dd2 = R.last ? p.dir_done : nullptr;
+      q.t = p.t + (uint64_t)k;
+      if (FULL) q.obs_full = p.traj_obs + k * slot_obs; else q.obs_image = p.traj_obs + k * slot_obs;
+      q.reward = reinterpret_cast<double*>(reinterpret_cast<char*>(p.traj_reward) + k * slot_rew);
+      q.dir_done = p.traj_dd + k * slot_dd;
+      q.actions_out = p.traj_actions ? p.traj_actions + k * slot_act : nullptr;
+      q.actions = p.actions ? p.actions + k * slot_act : nullptr;
+#ifdef MG_PHASE_TIMERS
+      uint32_t ph_acc[kPhases] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+      dyn_chunk<A, V, FULL, PRE, DEC, true>(q, dist, lut, base, pidx, cpc, stage, gw, lane, c * kWave, cur, cur, -1, err MG_PH_ARG, &S, &R);
+    }
+  }
   if (err) atomicOr(p.err, err);
 }
 

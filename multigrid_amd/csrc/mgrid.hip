@@ -1171,9 +1171,12 @@ const Variant kVariants[] = {
 
 // mutable-grid kernel instantiations
 // fn[0] decodes a view cell through the LDS table, fn[1] arithmetically (DEC, mg_dyn.h); the fully observed kinds have no views
-struct DynVariant { int A, V; bool full; int pre; kernel_fn fn[2]; };
+// roll[] = the fused K-step rollout of the same instantiation (mg_dyn_rollout_kernel)
+struct DynVariant { int A, V; bool full; int pre; kernel_fn fn[2], roll[2]; };
 #define MG_DYN(A, V, FULL, PRE) {A, FULL ? 0 : V, FULL, PRE, {mg_dyn_kernel<A, V, FULL, PRE, false>, \
-                                 FULL ? (kernel_fn) nullptr : (kernel_fn)mg_dyn_kernel<A, V, FULL, PRE, !FULL>}}
+                                 FULL ? (kernel_fn) nullptr : (kernel_fn)mg_dyn_kernel<A, V, FULL, PRE, !FULL>}, \
+                                 {mg_dyn_rollout_kernel<A, V, FULL, PRE, false>, \
+                                  FULL ? (kernel_fn) nullptr : (kernel_fn)mg_dyn_rollout_kernel<A, V, FULL, PRE, !FULL>}}
 const DynVariant kDynVariants[] = {
 #ifdef MG_MIN_BUILD
     MG_DYN(3, 7, false, 16), MG_DYN(2, 7, false, 16), MG_DYN(3, 5, false, 64), MG_DYN(3, 5, true, 16), MG_DYN(3, 5, true, 64),
@@ -1324,6 +1327,7 @@ struct mg_handle {
   uint8_t* obs_full;
   bool full_obs;
   int dyn_waves_cu2[2];  // waves of the mutable-grid kernel (table-decoding / arithmetic) a CU can hold by registers
+  int dyn_roll_waves_cu2[2];   // the same for the fused rollout kernels
   bool dyn_dec;          // this layout family's views decode their cell codes arithmetically (DEC, mg_dyn.h)
   int fixed_mode; uint64_t fixed_pd; uint32_t fixed_pd_hi;       // mg_set_fixed_spawn
   std::vector<uint8_t> free_cells;         // host copy: cell (y*W + x) holds nothing (placement checks)
@@ -1431,7 +1435,7 @@ int dyn_dec_index(const mg_handle* h) {
 
 // Mutable-grid launch geometry: 4 waves per workgroup (fewer for small batches), as many workgroups
 // per CU as LDS allows; persistent over chunks.
-void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* lds_out) {
+void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* lds_out, bool roll = false) {
   const mg_config& c = h->cfg;
   const size_t rowb = h->full_obs ? 0 : (size_t)c.view_size * c.view_size * 3;   // fully observed images are not staged
   const size_t fixed = ((size_t)h->LW * h->LH * 8 + (size_t)c.width * c.height * 4 + 256 * 4 + (size_t)h->GW * 4 + 8 + 15) / 16 * 16;
@@ -1440,7 +1444,7 @@ void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* l
   // (queried from the code object at mg_create: 512 VGPRs per SIMD lane / the kernel's count, x 4 SIMDs), and
   // whatever fits 160 KB of LDS.  Ties go to the smaller workgroup; small batches shrink it further so that
   // every CU gets work.
-  const int kDynWavesPerCU = h->dyn_waves_cu2[dyn_dec_index(h)];
+  const int kDynWavesPerCU = (roll ? h->dyn_roll_waves_cu2 : h->dyn_waves_cu2)[dyn_dec_index(h)];
   int nw = 1, best = 0;
   for (int cand = 1; cand <= 8; ++cand) {
     const size_t need = fixed + cand * per_wave;
@@ -1525,6 +1529,18 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     if (dest) {
       if (h->full_obs) p.obs_full = dest->obs_image; else p.obs_image = dest->obs_image;
       p.reward = dest->reward; p.dir_done = dest->dir_done;
+    }
+    if (n_roll > 0) {
+      // Fused rollout on mutable grids (mg_dyn_rollout_kernel): the trajectory is written once, so every image is streamed
+      p.n_roll = n_roll;
+      p.traj_obs = roll->obs_image; p.traj_reward = roll->reward; p.traj_dd = roll->dir_done;
+      p.traj_actions = actions ? nullptr : reinterpret_cast<uint32_t*>(roll->actions);
+      p.nt_obs = 0xFF;
+      if (const char* e = debug_env("MG_DEBUG_NT")) p.nt_obs = atoi(e);   // tuning experiments only
+      dyn_geometry(h, &nw, &grid, &lds, true);
+      hipLaunchKernelGGL(h->dvar->roll[dyn_dec_index(h)], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
+      HIP_TRY(hipGetLastError());
+      return launch_ep_stats(h, op, mask, n_roll, roll);
     }
     dyn_geometry(h, &nw, &grid, &lds);
     hipLaunchKernelGGL(h->dvar->fn[dyn_dec_index(h)], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
@@ -1678,11 +1694,13 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   h->full_obs = c.env_kind == MG_KIND_MEETUP; h->LW = c.width; h->LH = c.height;
   h->ep_on = false; h->ep_thr = 0.0; memset(&h->ep, 0, sizeof(h->ep));
   h->dyn_waves_cu2[0] = h->dyn_waves_cu2[1] = 8; h->dyn_dec = false; h->fixed_mode = 0; h->fixed_pd = 0; h->fixed_pd_hi = 0;
-  for (int v = 0; dvar && v < 2; ++v) {
+  h->dyn_roll_waves_cu2[0] = h->dyn_roll_waves_cu2[1] = 8;
+  for (int v = 0; dvar && v < 4; ++v) {
     hipFuncAttributes fa;
-    if (dvar->fn[v] && hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(dvar->fn[v])) == hipSuccess && fa.numRegs > 0) {
+    const kernel_fn fn = v < 2 ? dvar->fn[v] : dvar->roll[v - 2];
+    if (fn && hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(fn)) == hipSuccess && fa.numRegs > 0) {
       const int regs = (fa.numRegs + 7) / 8 * 8;                  // gfx950: 512 VGPRs per SIMD lane, allocated in 8s
-      h->dyn_waves_cu2[v] = 4 * std::max(1, std::min(8, 512 / regs));
+      (v < 2 ? h->dyn_waves_cu2[v] : h->dyn_roll_waves_cu2[v - 2]) = 4 * std::max(1, std::min(8, 512 / regs));
     }
   }
   // DoorKey's door row rides in five bits of the state word (mg_dyn.h): grids up to 33 rows; Cluttered / FourRooms
@@ -2148,8 +2166,14 @@ int mg_rollout(mg_handle* h, int32_t n_steps, const void* actions, const mg_roll
   if (!out->obs_image || !out->reward || !out->dir_done) return fail(MG_EINVAL, "obs_image, reward and dir_done of mg_rollout_out must be set");
   if (h->buf.env_reward) return fail(MG_EUNSUPPORTED, "mg_rollout / mg_rollout_random have no env_reward output (emit_env_reward = 0)");
   if (!h->have_reset) return fail(MG_ESTATE, "mg_reset must be called before mg_rollout / mg_rollout_random");
+  if (h->dynamic && h->dvar->roll[dyn_dec_index(h)] && !debug_env("MG_DEBUG_DYN_ROLL_STEPS")) {
+    // Mutable-grid kinds: the fused kernel of mg_dyn.h (a chunk's grids stay in LDS over the n_steps steps)
+    int rc = launch(h, OP_STEP, actions, nullptr, nullptr, nullptr, nullptr, actions ? 0 : 1, nullptr, nullptr, nullptr, nullptr, n_steps, out);
+    if (rc == MG_OK) h->t += (uint64_t)n_steps;
+    return rc;
+  }
   if (h->dynamic) {
-    // Mutable-grid kinds have no fused kernel (their grids live in LDS for one step at a time): the same n_steps steps as n_steps
+    // MG_DEBUG_DYN_ROLL_STEPS (tests / A-B timing: the round-2 form): the same n_steps steps as n_steps
     // launches of the step kernel, each writing straight into its trajectory slot (launch()'s `dest`); the last one writes the
     // handle's own buffers, which are then copied into the last slot (same stream: one full-size obs / reward / dir-done copy
     // per call, the price of leaving the handle exactly where n_steps single calls would).  Same contract, one launch per step.

@@ -169,8 +169,8 @@ def _twin_check(env, twin, traj, k, A, n, w):
 @pytest.mark.parametrize('env_id,kw', [('MultiGrid-DoorKey-6x6-v0', dict(max_steps=40)), ('MultiGrid-Meetup-Empty-6x6-v0', dict(max_steps=30)),
                                        ('MultiGrid-Cluttered-v0', dict(max_steps=25)), ('playground', {})])
 def test_rollout_on_mutable_grid_handles(playground_cells, env_id, kw):
-  """mg_rollout / mg_rollout_random on the mutable-grid kinds: same contract, run as one step-kernel launch per step — every slot
-  against a twin handle taking the same steps one call at a time, and the two handles' state afterwards."""
+  """mg_rollout / mg_rollout_random on the mutable-grid kinds (the fused kernel of mg_dyn.h since round 3): every slot against a
+  twin handle taking the same steps one call at a time, and the two handles' state afterwards."""
   _need_gpu()
   import multigrid_amd
   from multigrid_amd.batched import BatchedMultiGrid
@@ -201,6 +201,112 @@ def test_rollout_on_mutable_grid_handles(playground_cells, env_id, kw):
   assert torch.equal(env.grid_kinds(), twin.grid_kinds()) and env.step_index == twin.step_index == 3 * K
   assert env.check_errors() == 0 and twin.check_errors() == 0
   env.close(); twin.close()
+
+
+def _dyn_oracle(spec, n, seed):
+  size = spec.get('size')
+  return c_oracle.OracleBatch(None, n, W=size, H=size, A=spec['n_agents'], V=spec['view_size'], max_steps=spec['max_steps'],
+                              see_through=int(spec['see_through_walls']), competitive=int(spec['competitive']), shaping=1,
+                              auto_reset=1, seed=seed, kind=spec['kind'], n_goals=spec.get('n_goals', 0),
+                              n_clutter=spec.get('n_clutter', 0), lava=spec.get('walls_are_lava', False),
+                              two_rooms=spec.get('two_rooms', False))
+
+
+# (id, envs, K, calls, MG_DEBUG_GRID): every mutable-grid instantiation family — view 7 / view 5 with 16 and with 64 prefetched
+# rows / fully observed, one to five agents — ragged batches, and few workgroups so that a wave takes several chunks in turn
+_FUSED_DYN = [('MultiGrid-DoorKey-6x6-v0', 1000, 37, 2, None), ('MultiGrid-DoorKey-8x8-v0', 700, 45, 2, '2'),
+              ('MultiGrid-DoorKey-16x16-v0', 300, 40, 1, None), ('MultiGrid-DoorKey-5x5-Single-v0', 130, 60, 1, None),
+              ('MultiGrid-Cluttered-v0', 900, 33, 2, '3'), ('MultiGrid-Cluttered-Single-6x6-v0', 500, 50, 1, None),
+              ('MultiGrid-FourRooms-v0', 333, 41, 1, None), ('MultiGrid-FourRooms-15x15-v0', 400, 35, 1, '1'),
+              ('MultiGrid-Meetup-Empty-6x6-v0', 640, 40, 2, '2'), ('MultiGrid-Meetup-Empty-15x15-v0', 200, 30, 1, None), ('MultiGrid-Meetup-Random-12x12-v0', 256, 30, 1, None),
+              ('MultiGrid-WallsAreLava-v0', 450, 40, 1, None)]
+
+
+@pytest.mark.parametrize('env_id,n,K,calls,grid', _FUSED_DYN)
+def test_fused_rollout_on_mutable_grids_matches_the_oracle(monkeypatch, env_id, n, K, calls, grid):
+  """mg_dyn_rollout_kernel: K fused free-running steps on per-env grids (layouts, pickups, doors, respawns, auto-resets inside
+  the launch) against the oracle stepping K times, every trajectory slot and the handle's state afterwards, bit for bit."""
+  _need_gpu()
+  from multigrid_amd import registry
+  if env_id not in registry.registered_ids():
+    pytest.skip('id not registered')
+  if grid:
+    monkeypatch.setenv('MG_DEBUG_GRID', grid)
+  spec = registry.spec(env_id)
+  ms = min(spec['max_steps'], 25)
+  seed = 5 + sum(map(ord, env_id)) % 1000
+  env = registry.make_batched(env_id, n, seed=seed, max_steps=ms)
+  spec['max_steps'] = ms
+  assert env.mutable_grid
+  orc = _dyn_oracle(spec, n, seed)
+  env.reset(); orc.reset()
+  A = spec['n_agents']
+  traj = None
+  for call in range(calls):
+    traj = env.rollout_random(K, out=traj)
+    full = env.obs_full is not None
+    img = traj['image'].cpu().numpy().reshape((K, n, -1) if full else (K, A, n, -1))
+    rew, dirs, done = traj['reward'].cpu().numpy(), traj['direction'].cpu().numpy(), traj['done'].cpu().numpy()
+    for k in range(K):
+      w = '%s call %d step %d' % (env_id, call, k)
+      orc.step(None)
+      assert np.array_equal(img[k], orc.obs_image[0, :n] if full else orc.obs_image[:, :n]), w + ' obs'
+      assert np.array_equal(rew[k].view(np.int64), orc.reward[:, :n].view(np.int64)), w + ' reward'
+      assert np.array_equal(dirs[k], orc.obs_dir[:, :n]) and np.array_equal(done[k], orc.done[:n]), w + ' dir/done'
+    # the handle is where K single steps leave it: state, grids, carried objects, and its own output buffers = the last slot
+    carry, kinds = orc.dyn_state()
+    assert np.array_equal(env.agent_state.cpu().numpy().view(np.uint32), orc.agent_state()[:, :n])
+    assert np.array_equal(env.grid_kinds().cpu().numpy(), kinds[:n])
+    assert np.array_equal(env.carry.cpu().numpy().view(np.uint32), carry[:n])
+    assert torch.equal(traj['image'][K - 1], env.obs_full if full else env.obs_image)
+    assert torch.equal(traj['reward'][K - 1].view(torch.int64), env.reward.view(torch.int64))
+    assert torch.equal(traj['done'][K - 1], env.done) and env.step_index == (call + 1) * K
+  assert env.check_errors() == 0 and orc.errors() == 0
+  env.close()
+
+
+def test_fused_rollout_on_per_env_maps_and_the_step_by_step_form(monkeypatch):
+  """Per-env layouts (mg_set_maps: table decode, per-env reset templates and shaper goals) through the fused kernel against the
+  oracle holding the same layouts — drawn actions, then a caller's action ring — and the round-2 form of the same calls
+  (MG_DEBUG_DYN_ROLL_STEPS: one step launch per slot) as a second implementation of the same trajectory."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  from multigrid_amd import layouts
+  from test_gpu_dyn import _random_layouts
+  W, H, A, V, n, K, max_steps = 9, 9, 3, 5, 500, 36, 20
+  cells = _random_layouts(np.random.default_rng(11), n, W, H, True)
+  acts = np.random.default_rng(4).integers(0, 7, size=(K, n, A)).astype(np.uint8)
+  out = []
+  for steps_form in (False, True):
+    if steps_form:
+      monkeypatch.setenv('MG_DEBUG_DYN_ROLL_STEPS', '1')
+    env = BatchedMultiGrid(layouts.empty_bordered(W, H, goal=(W - 2, H - 2)), n_envs=n, n_agents=A, view_size=V, max_steps=max_steps, seed=17)
+    env.set_maps(cells)
+    orc = c_oracle.OracleBatch(cells[0], n, W=W, H=H, A=A, V=V, max_steps=max_steps, shaping=1, auto_reset=1, seed=17)
+    orc.set_maps(cells)
+    env.reset(); orc.reset()
+    t1 = env.rollout_random(K)
+    t2 = env.rollout(torch.from_numpy(acts).to(env.device))
+    for k in range(2 * K):
+      t, kk = (t1, k) if k < K else (t2, k - K)
+      if k < K:
+        orc.step(None)
+      else:
+        pad = np.full((A, orc.stride), 6, np.uint8)
+        pad[:, :n] = acts[kk].T
+        orc.step(pad)
+      assert np.array_equal(t['image'][kk].cpu().numpy().reshape(A, n, -1), orc.obs_image[:, :n]), (steps_form, k)
+      assert np.array_equal(t['reward'][kk].cpu().numpy().view(np.int64), orc.reward[:, :n].view(np.int64)), (steps_form, k)
+      assert np.array_equal(t['done'][kk].cpu().numpy(), orc.done[:n]), (steps_form, k)
+    carry, kinds = orc.dyn_state()
+    assert np.array_equal(env.agent_state.cpu().numpy().view(np.uint32), orc.agent_state()[:, :n])
+    assert np.array_equal(env.grid_kinds().cpu().numpy(), kinds[:n]) and np.array_equal(env.carry.cpu().numpy().view(np.uint32), carry[:n])
+    out.append(dict(img1=t1['image'].clone(), act1=t1['actions'].clone(), img2=t2['image'].clone(), dir2=t2['direction'].clone(),
+                    obs=env.obs_image.clone(), rew=env.reward.view(torch.int64).clone()))
+    assert env.check_errors() == 0 and orc.errors() == 0
+    env.close()
+  for k in out[0]:
+    assert torch.equal(out[0][k], out[1][k]), k
 
 
 @pytest.mark.parametrize('path', ['generic', 'table'])
