@@ -233,6 +233,92 @@ def load(path):
   return rec
 
 
+# ---- per-episode digests -----------------------------------------------------------------------------------------
+# A recording too large to commit whole (10 240 episodes: 25 MB of expected obs) is committed as its INPUTS (spawn / actions /
+# order / respawn ...) plus one 128-bit checksum per episode of everything a replay must reproduce.  The checksum is a
+# position-sensitive polynomial hash in uint64 arithmetic (two lanes with different multipliers), vectorised over episodes:
+#     h <- h * P + sum_i byte_i * M[i] + C(key)            for every (key, step) in replay order, live episodes only
+# with M a splitmix64 stream forced odd.  Not cryptographic — a transmission checksum, like a CRC, over data this build wrote.
+_DIGEST_P = (np.uint64(0x9E3779B97F4A7C15), np.uint64(0xC2B2AE3D27D4EB4F))
+_DIGEST_KEYS = ('obs_image', 'obs_dir', 'env_reward', 'shaped_reward', 'done', 'agent_pos', 'agent_dir', 'carry')
+_DIGEST_DROP = _DIGEST_KEYS          # what strip_to_digest removes from a recording
+
+
+def _splitmix64(n, seed):
+  out = np.empty(n, np.uint64)
+  x = seed & 0xFFFFFFFFFFFFFFFF
+  for i in range(n):
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    out[i] = (z ^ (z >> 31)) | 1
+  return out
+
+
+class EpisodeDigest:
+  """128-bit running checksum per episode; update() is called in replay order with the [E, ...] values of one key at one step."""
+
+  def __init__(self, E):
+    self.h = np.zeros((E, 2), np.uint64)
+    self._m = {}
+
+  def _mult(self, n):
+    if n not in self._m:
+      self._m[n] = (_splitmix64(n, 1), _splitmix64(n, 2))
+    return self._m[n]
+
+  def update(self, key, values, live):
+    v = np.asarray(values)
+    if v.dtype == np.float64:
+      v = v.view(np.int64)
+    elif v.dtype != np.int64:
+      v = v.astype(np.uint8)                    # obs bytes, directions, positions, done flags, carried kinds
+    E = self.h.shape[0]
+    x = np.ascontiguousarray(v).reshape(E, -1).view(np.uint8).astype(np.uint64)
+    c = np.uint64(_DIGEST_KEYS.index(key) + 1)
+    with np.errstate(over='ignore'):
+      for lane in range(2):
+        r = (x * self._mult(x.shape[1])[lane]).sum(axis=1, dtype=np.uint64)
+        self.h[live, lane] = self.h[live, lane] * _DIGEST_P[lane] + r[live] + c
+
+
+def digest_recording(rec):
+  """The per-episode checksums of a full recording, in the order the replays visit its values."""
+  E, T, A = rec['actions'].shape
+  d = EpisodeDigest(E)
+  every = rec['length'] >= 0
+  d.update('obs_image', rec['obs_image'][:, 0], every)
+  d.update('obs_dir', rec['obs_dir'][:, 0], every)
+  meta = rec['meta'] if isinstance(rec['meta'], dict) else json.loads(str(rec['meta']))
+  mutable = meta['kind'] != 'static'           # (a static layout with objects also runs on mutable grids; its carry words are not summed)
+  for t in range(T):
+    live = rec['length'] > t
+    if not live.any():
+      break
+    d.update('obs_image', rec['obs_image'][:, t + 1], live)
+    d.update('obs_dir', rec['obs_dir'][:, t + 1], live)
+    d.update('env_reward', rec['env_reward'][:, t], live)
+    if 'shaped_reward' in rec:
+      d.update('shaped_reward', rec['shaped_reward'][:, t], live)
+    d.update('done', rec['done'][:, t], live)
+    d.update('agent_pos', rec['agent_pos'][:, t + 1], live)
+    d.update('agent_dir', rec['agent_dir'][:, t + 1], live)
+    if mutable and 'carry' in rec:
+      d.update('carry', rec['carry'][:, t + 1], live)
+  return d.h
+
+
+def strip_to_digest(rec):
+  """A recording reduced to its inputs + `digest` uint64[E, 2] (+ `shaped` / `touches` for the tests' sanity checks)."""
+  out = {k: v for k, v in rec.items() if k not in _DIGEST_DROP}
+  out['digest'] = digest_recording(rec)
+  out['shaped'] = np.array('shaped_reward' in rec)
+  out['has_carry'] = np.array('carry' in rec)
+  out['touches'] = np.array(int((rec['env_reward'] > 0).sum()), np.int64)
+  return out
+
+
 def replay_on_device(rec, device=0, check_state=True):
   """Replay a fixture through libmgrid.so (one device env per episode, replay mode, no auto-reset) and
   compare every recorded output bit for bit.  Returns {'episodes', 'steps', 'mismatches': {name: count}}."""
@@ -240,7 +326,8 @@ def replay_on_device(rec, device=0, check_state=True):
   from .batched import BatchedMultiGrid
   m = rec['meta']
   E, T, A = rec['actions'].shape
-  shaped = 'shaped_reward' in rec
+  dig = EpisodeDigest(E) if 'digest' in rec else None        # a digest fixture (strip_to_digest): checksums instead of arrays
+  shaped = bool(rec['shaped']) if dig is not None else 'shaped_reward' in rec
   kw = dict(n_envs=E, n_agents=A, view_size=m['view_size'], max_steps=m['max_steps'],
             see_through_walls=bool(m.get('see_through_walls', False)), competitive=bool(m.get('competitive', False)),
             shaping=(m.get('shaping') if m.get('shaping') in ('v7', 'v8') else 'v8') if shaped else None, auto_reset=False,
@@ -259,7 +346,13 @@ def replay_on_device(rec, device=0, check_state=True):
   am = lambda x: torch.from_numpy(np.ascontiguousarray(np.moveaxis(x, 0, 1))).to(dev)   # [E, A, ...] -> [A, E, ...]
   bad = {}
 
-  def cmp(name, got, want, live):
+  def cmp(name, got, key, idx, live):
+    if dig is not None:
+      dig.update(key, got, live)
+      return
+    want = rec[key][:, idx]
+    if want.dtype == np.float64:
+      want = want.view(np.int64)
     n = int((np.asarray(got)[live] != np.asarray(want)[live]).sum())
     if n:
       bad[name] = bad.get(name, 0) + n
@@ -277,8 +370,8 @@ def replay_on_device(rec, device=0, check_state=True):
     else:
       env.reset(spawn=am(rec['spawn']))
     live = rec['length'] >= 0
-    cmp('obs_image[0]', images(), rec['obs_image'][:, 0], live)
-    cmp('obs_dir[0]', env.obs_dir.cpu().numpy().T, rec['obs_dir'][:, 0], live)
+    cmp('obs_image[0]', images(), 'obs_image', 0, live)
+    cmp('obs_dir[0]', env.obs_dir.cpu().numpy().T, 'obs_dir', 0, live)
     steps = 0
     for t in range(T):
       live = rec['length'] > t
@@ -291,22 +384,26 @@ def replay_on_device(rec, device=0, check_state=True):
       extra = dict(objdrop=am(rec['objdrop'][:, t])) if env.mutable_grid else {}
       env.step_replay(am(act), am(order), am(rec['respawn'][:, t]), **extra)
       steps += int(live.sum())
-      cmp('obs_image', images(), rec['obs_image'][:, t + 1], live)
-      cmp('obs_dir', env.obs_dir.cpu().numpy().T, rec['obs_dir'][:, t + 1], live)
-      cmp('env_reward', env.env_reward.cpu().numpy().T.view(np.int64), rec['env_reward'][:, t].view(np.int64), live)
+      cmp('obs_image', images(), 'obs_image', t + 1, live)
+      cmp('obs_dir', env.obs_dir.cpu().numpy().T, 'obs_dir', t + 1, live)
+      cmp('env_reward', np.ascontiguousarray(env.env_reward.cpu().numpy().T).view(np.int64), 'env_reward', t, live)
       if shaped:
-        cmp('shaped_reward', env.reward.cpu().numpy().T.view(np.int64), rec['shaped_reward'][:, t].view(np.int64), live)
-      cmp('done', env.done.cpu().numpy(), rec['done'][:, t], live)
-      if check_state:
-        cmp('agent_pos', env.agent_pos.cpu().numpy().transpose(1, 0, 2), rec['agent_pos'][:, t + 1], live)
-        cmp('agent_dir', env.agent_dir.cpu().numpy().T, rec['agent_dir'][:, t + 1], live)
-        if env.mutable_grid and 'carry' in rec:
+        cmp('shaped_reward', np.ascontiguousarray(env.reward.cpu().numpy().T).view(np.int64), 'shaped_reward', t, live)
+      cmp('done', env.done.cpu().numpy(), 'done', t, live)
+      if check_state or dig is not None:
+        cmp('agent_pos', env.agent_pos.cpu().numpy().transpose(1, 0, 2), 'agent_pos', t + 1, live)
+        cmp('agent_dir', env.agent_dir.cpu().numpy().T, 'agent_dir', t + 1, live)
+        if (env.mutable_grid and 'carry' in rec) if dig is None else (m['kind'] != 'static' and bool(rec['has_carry'])):
           c = env.carry.cpu().numpy().view(np.uint32).reshape(E, -1)      # one word per env, two with five agents
           got = np.stack([(c[:, a // 4] >> (8 * (a % 4))) & 255 for a in range(A)], axis=1)
-          cmp('carry', got, rec['carry'][:, t + 1], live)
+          cmp('carry', got, 'carry', t + 1, live)
     err = env.check_errors()
     if err:
       bad['device_error_word'] = err
+    if dig is not None:
+      n = int((dig.h != rec['digest']).any(axis=1).sum())
+      if n:
+        bad['episode_digest'] = n
   finally:
     env.close()
   return {'episodes': int(E), 'steps': steps, 'mismatches': bad}

@@ -75,6 +75,84 @@ def test_reference_recorded_fixtures_say_what_they_are(name):
     assert int(((rec['carry'][:, 1:] != 0) & (rec['carry'][:, :-1] == 0)).sum()) > 5 and int((rec['objdrop'][..., 0] >= 0).sum()) > 5
 
 
+# BASELINE's "10k replayed episodes", recorded from the reference's own env code over the stand-ins (same caveat as REF_L0_FIXTURES)
+# by tests/golden/make_refL0_digest_fixture.py: inputs + one 128-bit checksum per episode of everything a replay must reproduce.
+DIGEST_FIXTURE = 'refL0_cluttered_fixed_10240_digest.npz'
+
+
+def digest_on_oracle_batch(rec):
+  """A shared-static-map fixture through oracle/mg_oracle.c (batch entry points, replay mode): per-episode checksums of its outputs
+  in the order recorder.digest_recording / replay_on_device visit them."""
+  m = rec['meta']
+  E, T, A = rec['actions'].shape
+  shaped = bool(rec['shaped']) if 'shaped' in rec else 'shaped_reward' in rec
+  assert m['kind'] == 'static'
+  orc = c_oracle.OracleBatch(rec['cells'], E, W=m['width'], H=m['height'], A=A, V=m['view_size'], max_steps=m['max_steps'],
+                             shaping=(2 if m.get('shaping') == 'v7' else 1) if shaped else 0, auto_reset=0)
+  S = orc.stride
+
+  def am(x, fill):                       # [E, A, ...] -> agent-major over the padded batch
+    out = np.full((A, S) + x.shape[2:], fill, x.dtype)
+    out[:, :E] = np.moveaxis(x, 0, 1)
+    return out
+  d = recorder.EpisodeDigest(E)
+
+  def state():
+    w = orc.agent_state()[:, :E].T
+    return np.stack([w & 63, (w >> 6) & 63], axis=-1).astype(np.uint8), ((w >> 12) & 3).astype(np.uint8)
+  orc.reset(spawn=am(rec['spawn'], 0))
+  every = rec['length'] >= 0
+  V = m['view_size']
+  d.update('obs_image', orc.obs_image[:, :E].transpose(1, 0, 2).reshape(E, A, V, V, 3), every)
+  d.update('obs_dir', orc.obs_dir[:, :E].T, every)
+  for t in range(T):
+    live = rec['length'] > t
+    if not live.any():
+      break
+    act = rec['actions'][:, t].copy(); act[~live] = 6
+    order = rec['order'][:, t].copy(); order[~live] = np.arange(A, dtype=np.uint8)
+    orc.step(am(act, 6), order=am(order, 0), respawn=am(rec['respawn'][:, t], -1))
+    d.update('obs_image', orc.obs_image[:, :E].transpose(1, 0, 2).reshape(E, A, V, V, 3), live)
+    d.update('obs_dir', orc.obs_dir[:, :E].T, live)
+    d.update('env_reward', np.ascontiguousarray(orc.env_reward[:, :E].T), live)
+    if shaped:
+      d.update('shaped_reward', np.ascontiguousarray(orc.reward[:, :E].T), live)
+    d.update('done', orc.done[:E], live)
+    pos, dirs = state()
+    d.update('agent_pos', pos, live)
+    d.update('agent_dir', dirs, live)
+  assert orc.errors() == 0
+  return d.h
+
+
+def test_digest_of_a_recording_is_what_a_replay_computes():
+  """The checksum scheme itself, on a small full fixture: the digest of the recorded arrays equals the digest the oracle replay
+  computes from the inputs alone, and one changed action changes that episode's digest and no other."""
+  rec = recorder.load(os.path.join(GOLDEN, 'refL0_cluttered_fixed.npz'))
+  want = recorder.digest_recording(rec)
+  slim = recorder.strip_to_digest(rec)
+  assert 'obs_image' not in slim and np.array_equal(slim['digest'], want)
+  assert np.array_equal(digest_on_oracle_batch(slim), want)
+  bad = dict(slim, actions=slim['actions'].copy())
+  e = 5
+  t = int(np.argmax(bad['actions'][e, :, 0] != 2))
+  bad['actions'][e, t, 0] = 2 if bad['actions'][e, t, 0] != 2 else 0
+  got = digest_on_oracle_batch(bad)
+  differs = (got != want).any(axis=1)
+  assert differs[e] and differs.sum() == 1
+
+
+def test_ten_thousand_reference_recorded_episodes_replay_on_the_c_oracle():
+  rec = recorder.load(os.path.join(GOLDEN, DIGEST_FIXTURE))
+  m = rec['meta']
+  E, T, A = rec['actions'].shape
+  assert E >= 10000 and T == 100 and A == 3 and m['source'].startswith('reference ') and 'unpinned' in m['caveat']
+  assert int(rec['touches']) > 1000 and int((rec['respawn'][..., 0] >= 0).sum()) > 1000       # goal touches and respawns are well represented
+  assert len({tuple(o) for o in rec['order'].reshape(-1, A)[:5000]}) == 6                       # all six agent orders occur
+  got = digest_on_oracle_batch(rec)
+  assert int((got != rec['digest']).any(axis=1).sum()) == 0
+
+
 def test_record_save_load_round_trip(tmp_path, cluttered_cells):
   A = 3
 
@@ -178,3 +256,16 @@ def test_v7_shaped_recording_replays_on_the_gpu(empty_cells, tmp_path):
   rec = _record_v7(empty_cells, tmp_path)
   rep = recorder.replay_on_device(rec)
   assert rep['mismatches'] == {}, rep
+
+
+@pytest.mark.gpu
+def test_ten_thousand_reference_recorded_episodes_replay_on_the_gpu():
+  """10 240 episodes x 100 steps recorded from the reference's own env code (over the stand-ins), one device env per episode in replay
+  mode: every obs byte, direction, float64 env and shaped reward bit pattern, done flag and agent position, via per-episode checksums."""
+  torch = pytest.importorskip('torch')
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  rec = recorder.load(os.path.join(GOLDEN, DIGEST_FIXTURE))
+  rep = recorder.replay_on_device(rec)
+  assert rep['mismatches'] == {}, rep
+  assert rep['episodes'] >= 10000 and rep['steps'] == rep['episodes'] * 100
