@@ -20,6 +20,8 @@ def main():
   ap.add_argument('--seed', type=int, default=777)
   ap.add_argument('--max-steps', type=int, default=60)
   ap.add_argument('--ids', default='')
+  ap.add_argument('--rollout', type=int, default=0, help='K > 0: take the steps K at a time through the fused rollout launch '
+                  '(mg_rollout_random; shared-map and mutable-grid kernels) instead of one launch per step')
   args = ap.parse_args()
   N, bad = args.envs, 0
   for k, env_id in enumerate(i for i in registry.registered_ids() if args.ids in i):
@@ -27,7 +29,7 @@ def main():
     spec = registry.spec(env_id)
     seed = args.seed + k
     ms = min(spec['max_steps'], args.max_steps)
-    env = registry.make_batched(env_id, N, seed=seed, emit_env_reward=True, max_steps=ms)
+    env = registry.make_batched(env_id, N, seed=seed, emit_env_reward=not args.rollout, max_steps=ms)
     spec['max_steps'] = ms
     size = spec.get('size')
     cells = env.cells if spec.get('kind', 'static') == 'static' else None
@@ -40,7 +42,22 @@ def main():
                                fixed_spawn=spec.get('fixed_spawn'), fixed_mode=fixed, two_rooms=spec.get('two_rooms', False))
     env.reset(); orc.reset()
     A, first = spec['n_agents'], None
-    for t in range(args.steps):
+    full = env.obs_full is not None
+    traj = None
+    for s0 in range(0, args.steps if args.rollout else 0, max(args.rollout, 1)):
+      K = min(args.rollout, args.steps - s0)
+      traj = env.rollout_random(K, out=traj if K == args.rollout else None)
+      img = traj['image'].cpu().numpy().reshape((K, N, -1) if full else (K, A, N, -1))
+      rew, dirs, done = traj['reward'].cpu().numpy(), traj['direction'].cpu().numpy(), traj['done'].cpu().numpy()
+      for k in range(K):
+        orc.step()
+        ok = (np.array_equal(img[k], orc.obs_image[0, :N] if full else orc.obs_image[:, :N]) and np.array_equal(dirs[k], orc.obs_dir[:, :N])
+              and np.array_equal(rew[k].view(np.int64), orc.reward[:, :N].view(np.int64)) and np.array_equal(done[k], orc.done[:N]))
+        if not ok and first is None:
+          first = s0 + k
+      if first is not None:
+        break
+    for t in range(0 if args.rollout else args.steps):
       env.step_random(); orc.step()
       img = env.obs_full.cpu().numpy().reshape(N, -1) if env.obs_full is not None else env.obs_image.cpu().numpy().reshape(A, N, -1)
       ref = orc.obs_image[0, :N] if env.obs_full is not None else orc.obs_image[:, :N]

@@ -81,29 +81,47 @@ DIGEST_FIXTURE = 'refL0_cluttered_fixed_10240_digest.npz'
 
 
 def digest_on_oracle_batch(rec):
-  """A shared-static-map fixture through oracle/mg_oracle.c (batch entry points, replay mode): per-episode checksums of its outputs
-  in the order recorder.digest_recording / replay_on_device visit them."""
+  """A fixture through oracle/mg_oracle.c (batch entry points, replay mode, every kind): per-episode checksums of its outputs in
+  the order recorder.digest_recording / replay_on_device visit them."""
   m = rec['meta']
   E, T, A = rec['actions'].shape
   shaped = bool(rec['shaped']) if 'shaped' in rec else 'shaped_reward' in rec
-  assert m['kind'] == 'static'
-  orc = c_oracle.OracleBatch(rec['cells'], E, W=m['width'], H=m['height'], A=A, V=m['view_size'], max_steps=m['max_steps'],
-                             shaping=(2 if m.get('shaping') == 'v7' else 1) if shaped else 0, auto_reset=0)
+  kind = m['kind']
+  full = kind == 'meetup'
+  orc = c_oracle.OracleBatch(rec.get('cells') if kind == 'static' else None, E, W=m['width'], H=m['height'], A=A, V=m['view_size'],
+                             max_steps=m['max_steps'], see_through=int(bool(m.get('see_through_walls', False))),
+                             competitive=int(bool(m.get('competitive', False))),
+                             shaping=(2 if m.get('shaping') == 'v7' else 1) if shaped else 0, auto_reset=0, kind=kind,
+                             n_goals=m.get('n_goals', 0), n_clutter=m.get('n_clutter', 0), lava=m.get('walls_are_lava', False),
+                             two_rooms=bool(m.get('two_rooms', False)))
   S = orc.stride
+  with_carry = kind != 'static' and (bool(rec['has_carry']) if 'has_carry' in rec else 'carry' in rec)
 
   def am(x, fill):                       # [E, A, ...] -> agent-major over the padded batch
     out = np.full((A, S) + x.shape[2:], fill, x.dtype)
     out[:, :E] = np.moveaxis(x, 0, 1)
     return out
+
+  def pad(x, fill=0):                    # [E, ...] -> the padded batch
+    out = np.full((S,) + x.shape[1:], fill, x.dtype)
+    out[:E] = x
+    return out
   d = recorder.EpisodeDigest(E)
+
+  def images():
+    if full:                             # one whole-grid image per env, A identical copies in a recording
+      return np.repeat(orc.obs_image[0, :E][:, None], A, axis=1)
+    return orc.obs_image[:, :E].transpose(1, 0, 2)
 
   def state():
     w = orc.agent_state()[:, :E].T
     return np.stack([w & 63, (w >> 6) & 63], axis=-1).astype(np.uint8), ((w >> 12) & 3).astype(np.uint8)
-  orc.reset(spawn=am(rec['spawn'], 0))
+  if kind in ('cluttered', 'meetup', 'fourrooms'):
+    orc.reset(spawn=am(rec['spawn'], 0), scatter=pad(rec['scatter']))
+  else:
+    orc.reset(spawn=am(rec['spawn'], 0), gen=pad(rec['gen']) if kind == 'doorkey' else None)
   every = rec['length'] >= 0
-  V = m['view_size']
-  d.update('obs_image', orc.obs_image[:, :E].transpose(1, 0, 2).reshape(E, A, V, V, 3), every)
+  d.update('obs_image', images(), every)
   d.update('obs_dir', orc.obs_dir[:, :E].T, every)
   for t in range(T):
     live = rec['length'] > t
@@ -111,8 +129,9 @@ def digest_on_oracle_batch(rec):
       break
     act = rec['actions'][:, t].copy(); act[~live] = 6
     order = rec['order'][:, t].copy(); order[~live] = np.arange(A, dtype=np.uint8)
-    orc.step(am(act, 6), order=am(order, 0), respawn=am(rec['respawn'][:, t], -1))
-    d.update('obs_image', orc.obs_image[:, :E].transpose(1, 0, 2).reshape(E, A, V, V, 3), live)
+    orc.step(am(act, 6), order=am(order, 0), respawn=am(rec['respawn'][:, t], -1),
+             objdrop=am(rec['objdrop'][:, t], -1))
+    d.update('obs_image', images(), live)
     d.update('obs_dir', orc.obs_dir[:, :E].T, live)
     d.update('env_reward', np.ascontiguousarray(orc.env_reward[:, :E].T), live)
     if shaped:
@@ -121,6 +140,9 @@ def digest_on_oracle_batch(rec):
     pos, dirs = state()
     d.update('agent_pos', pos, live)
     d.update('agent_dir', dirs, live)
+    if with_carry:
+      c = orc.dyn_state()[0][:E].reshape(E, -1)
+      d.update('carry', np.stack([(c[:, a // 4] >> (8 * (a % 4))) & 255 for a in range(A)], axis=1), live)
   assert orc.errors() == 0
   return d.h
 
@@ -140,6 +162,31 @@ def test_digest_of_a_recording_is_what_a_replay_computes():
   got = digest_on_oracle_batch(bad)
   differs = (got != want).any(axis=1)
   assert differs[e] and differs.sum() == 1
+
+
+# The other kinds at a size the full fixtures cannot have (tests/golden/make_refL0_digest_fixture.py, same caveat): DoorKey with key /
+# door / goal-seeking agents, Meetup, per-env random Cluttered layouts, FourRooms.
+KIND_DIGEST_FIXTURES = ['refL0_doorkey_6x6_1024_digest.npz', 'refL0_doorkey_8x8_1024_digest.npz', 'refL0_meetup_8x8_1024_digest.npz',
+                        'refL0_cluttered_v0_1024_digest.npz', 'refL0_fourrooms_15x15_1024_digest.npz']
+
+
+@pytest.mark.parametrize('name', ['refL0_doorkey_6x6.npz', 'refL0_meetup_8x8.npz', 'replay_playground_9x9.npz', 'replay_fourrooms_9x9.npz'])
+def test_digest_scheme_on_the_mutable_grid_kinds(name):
+  """digest of the recorded arrays == digest the batch oracle computes from the inputs alone, for the kinds with layouts, objects
+  and carried kinds (the full fixtures of those kinds, which the per-episode oracle replay above also takes)."""
+  rec = recorder.load(os.path.join(GOLDEN, name))
+  slim = recorder.strip_to_digest(rec)
+  assert np.array_equal(digest_on_oracle_batch(slim), recorder.digest_recording(rec))
+
+
+@pytest.mark.parametrize('name', KIND_DIGEST_FIXTURES)
+def test_reference_recorded_digest_fixtures_replay_on_the_c_oracle(name):
+  rec = recorder.load(os.path.join(GOLDEN, name))
+  m = rec['meta']
+  assert m['source'].startswith('reference ') and 'unpinned' in m['caveat'] and len(rec['length']) >= 1000
+  assert int(rec['touches']) > 100
+  got = digest_on_oracle_batch(rec)
+  assert int((got != rec['digest']).any(axis=1).sum()) == 0
 
 
 def test_ten_thousand_reference_recorded_episodes_replay_on_the_c_oracle():
@@ -256,6 +303,18 @@ def test_v7_shaped_recording_replays_on_the_gpu(empty_cells, tmp_path):
   rec = _record_v7(empty_cells, tmp_path)
   rep = recorder.replay_on_device(rec)
   assert rep['mismatches'] == {}, rep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', KIND_DIGEST_FIXTURES)
+def test_reference_recorded_digest_fixtures_replay_on_the_gpu(name):
+  torch = pytest.importorskip('torch')
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  rec = recorder.load(os.path.join(GOLDEN, name))
+  rep = recorder.replay_on_device(rec)
+  assert rep['mismatches'] == {}, rep
+  assert rep['episodes'] >= 1000 and rep['steps'] == int(rec['length'].sum())
 
 
 @pytest.mark.gpu
