@@ -74,7 +74,7 @@ def kernel_source_hash():
   measured on, so that a stale profiles/*_traffic.json is visible in the bench line."""
   import hashlib
   h = hashlib.sha256()
-  for f in ('mgrid.hip', 'mg_dyn.h', 'mg_vis.h'):
+  for f in ('mgrid.hip', 'mg_dyn.h', 'mg_vis.h', 'mgrid_dynroll.hip'):
     with open(os.path.join(ROOT, 'multigrid_amd', 'csrc', f), 'rb') as fh:
       h.update(fh.read())
   return h.hexdigest()[:12]

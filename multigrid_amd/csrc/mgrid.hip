@@ -1048,6 +1048,37 @@ __global__ __launch_bounds__(kMaxBlock) void mg_rollout_kernel(const Params p) {
 
 #include "mg_dyn.h"
 
+// The instantiations of the mutable-grid kernels, one to five agents for view 7, one to four for view 5 and the fully observed
+// kinds (no views; the V parameter is unused), with 16 or 64 prefetched grid rows.  X(A, V, FULL, PRE).
+// MG_MIN_BUILD (tools/gpu.sh build ... -DMG_MIN_BUILD): only what tools/kbench times — quick A/B builds, never the product
+#ifdef MG_MIN_BUILD
+#define MG_DYN_LIST(X) X(3, 7, false, 16) X(2, 7, false, 16) X(3, 5, false, 64) X(3, 5, true, 16) X(3, 5, true, 64)
+#else
+#define MG_DYN_LIST(X) \
+    X(1, 7, false, 16) X(2, 7, false, 16) X(3, 7, false, 16) X(4, 7, false, 16) X(5, 7, false, 16) \
+    X(1, 5, false, 16) X(2, 5, false, 16) X(3, 5, false, 16) X(4, 5, false, 16) \
+    X(1, 5, false, 64) X(2, 5, false, 64) X(3, 5, false, 64) \
+    X(1, 5, true, 16) X(2, 5, true, 16) X(3, 5, true, 16) X(4, 5, true, 16) \
+    X(1, 5, true, 64) X(2, 5, true, 64) X(3, 5, true, 64)
+#endif
+
+#ifdef MG_TU_DYNROLL
+// ---- second translation unit (mgrid_dynroll.hip): nothing but the fused mutable-grid rollout kernels and their lookup ----
+struct DynRollEntry { int A, V; bool full; int pre; const void* fn[2]; };
+#define MG_DYN_ROLL(A, V, FULL, PRE) {A, FULL ? 0 : V, FULL, PRE, {(const void*)mg_dyn_rollout_kernel<A, V, FULL, PRE, false>, \
+                                      FULL ? (const void*)nullptr : (const void*)mg_dyn_rollout_kernel<A, V, FULL, PRE, !FULL>}},
+const DynRollEntry kDynRoll[] = { MG_DYN_LIST(MG_DYN_ROLL) };
+}  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) const void* mg_dynroll_kernel(int A, int V, int full, int pre, int dec) {
+  for (const DynRollEntry& e : kDynRoll)
+    if (e.A == A && e.V == V && e.full == (full != 0) && e.pre == pre) return e.fn[dec ? 1 : 0];
+  return nullptr;
+}
+#else
+// (defined in mgrid_dynroll.hip's translation unit; C linkage, hidden: not part of the library's ABI)
+extern "C" __attribute__((visibility("hidden"))) const void* mg_dynroll_kernel(int A, int V, int full, int pre, int dec);
+
 // ---------------------------------------------------------------------------------------------
 // mg_step_noalloc: the per-GPU scratch its kernels use instead of a handle's hipMalloc'ed tables.
 // Layout: [0, 256) the error word (+ padding), [256, 256 + 32 KB) the goal-distance LUT (W*H f64, W, H <= 64),
@@ -1170,25 +1201,15 @@ const Variant kVariants[] = {
 };
 
 // mutable-grid kernel instantiations
-// fn[0] decodes a view cell through the LDS table, fn[1] arithmetically (DEC, mg_dyn.h); the fully observed kinds have no views
-// roll[] = the fused K-step rollout of the same instantiation (mg_dyn_rollout_kernel)
-struct DynVariant { int A, V; bool full; int pre; kernel_fn fn[2], roll[2]; };
+// fn[0] decodes a view cell through the LDS table, fn[1] arithmetically (DEC, mg_dyn.h); the fully observed kinds have no views.
+// The fused rollout kernels of the same instantiations (mg_dyn_rollout_kernel) live in a code object of their own
+// (mgrid_dynroll.hip, looked up through mg_dynroll_kernel at mg_create): with them in this one — 38 more kernels, 4.3 MB of code
+// instead of 3.3 — the shared-map headline kernel, whose ISA and descriptor were bit-identical, ran 1.3 % slower (50.83 against
+// 50.15 us at 1M envs, interleaved in one process, profiles/r3_product_vs_session_start_static_ab.txt).
+struct DynVariant { int A, V; bool full; int pre; kernel_fn fn[2]; };
 #define MG_DYN(A, V, FULL, PRE) {A, FULL ? 0 : V, FULL, PRE, {mg_dyn_kernel<A, V, FULL, PRE, false>, \
-                                 FULL ? (kernel_fn) nullptr : (kernel_fn)mg_dyn_kernel<A, V, FULL, PRE, !FULL>}, \
-                                 {mg_dyn_rollout_kernel<A, V, FULL, PRE, false>, \
-                                  FULL ? (kernel_fn) nullptr : (kernel_fn)mg_dyn_rollout_kernel<A, V, FULL, PRE, !FULL>}}
-const DynVariant kDynVariants[] = {
-#ifdef MG_MIN_BUILD
-    MG_DYN(3, 7, false, 16), MG_DYN(2, 7, false, 16), MG_DYN(3, 5, false, 64), MG_DYN(3, 5, true, 16), MG_DYN(3, 5, true, 64),
-#else
-    MG_DYN(1, 7, false, 16), MG_DYN(2, 7, false, 16), MG_DYN(3, 7, false, 16), MG_DYN(4, 7, false, 16), MG_DYN(5, 7, false, 16),
-    MG_DYN(1, 5, false, 16), MG_DYN(2, 5, false, 16), MG_DYN(3, 5, false, 16), MG_DYN(4, 5, false, 16),
-    MG_DYN(1, 5, false, 64), MG_DYN(2, 5, false, 64), MG_DYN(3, 5, false, 64),
-    // fully observed kinds (no views; the V parameter is unused)
-    MG_DYN(1, 5, true, 16), MG_DYN(2, 5, true, 16), MG_DYN(3, 5, true, 16), MG_DYN(4, 5, true, 16),
-    MG_DYN(1, 5, true, 64), MG_DYN(2, 5, true, 64), MG_DYN(3, 5, true, 64),
-#endif
-};
+                                 FULL ? (kernel_fn) nullptr : (kernel_fn)mg_dyn_kernel<A, V, FULL, PRE, !FULL>}},
+const DynVariant kDynVariants[] = { MG_DYN_LIST(MG_DYN) };
 
 // Host twin of static_view<V>: the static view of (x, y, dir) as a table entry
 // (NW stream dwords of 3-byte codes with visibility applied, then the visibility bit mask).
@@ -1328,6 +1349,7 @@ struct mg_handle {
   bool full_obs;
   int dyn_waves_cu2[2];  // waves of the mutable-grid kernel (table-decoding / arithmetic) a CU can hold by registers
   int dyn_roll_waves_cu2[2];   // the same for the fused rollout kernels
+  const void* dyn_roll_fn[2];  // those kernels (mgrid_dynroll.hip's code object), null where there is none
   bool dyn_dec;          // this layout family's views decode their cell codes arithmetically (DEC, mg_dyn.h)
   int fixed_mode; uint64_t fixed_pd; uint32_t fixed_pd_hi;       // mg_set_fixed_spawn
   std::vector<uint8_t> free_cells;         // host copy: cell (y*W + x) holds nothing (placement checks)
@@ -1538,8 +1560,8 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
       p.nt_obs = 0xFF;
       if (const char* e = debug_env("MG_DEBUG_NT")) p.nt_obs = atoi(e);   // tuning experiments only
       dyn_geometry(h, &nw, &grid, &lds, true);
-      hipLaunchKernelGGL(h->dvar->roll[dyn_dec_index(h)], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
-      HIP_TRY(hipGetLastError());
+      void* kargs[] = {&p};
+      HIP_TRY(hipLaunchKernel(h->dyn_roll_fn[dyn_dec_index(h)], dim3(grid), dim3(nw * kWave), kargs, lds, h->stream));
       return launch_ep_stats(h, op, mask, n_roll, roll);
     }
     dyn_geometry(h, &nw, &grid, &lds);
@@ -1695,10 +1717,11 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   h->ep_on = false; h->ep_thr = 0.0; memset(&h->ep, 0, sizeof(h->ep));
   h->dyn_waves_cu2[0] = h->dyn_waves_cu2[1] = 8; h->dyn_dec = false; h->fixed_mode = 0; h->fixed_pd = 0; h->fixed_pd_hi = 0;
   h->dyn_roll_waves_cu2[0] = h->dyn_roll_waves_cu2[1] = 8;
+  for (int v = 0; v < 2; ++v) h->dyn_roll_fn[v] = dvar ? mg_dynroll_kernel(dvar->A, dvar->V, dvar->full ? 1 : 0, dvar->pre, v) : nullptr;
   for (int v = 0; dvar && v < 4; ++v) {
     hipFuncAttributes fa;
-    const kernel_fn fn = v < 2 ? dvar->fn[v] : dvar->roll[v - 2];
-    if (fn && hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(fn)) == hipSuccess && fa.numRegs > 0) {
+    const void* fn = v < 2 ? reinterpret_cast<const void*>(dvar->fn[v]) : h->dyn_roll_fn[v - 2];
+    if (fn && hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.numRegs > 0) {
       const int regs = (fa.numRegs + 7) / 8 * 8;                  // gfx950: 512 VGPRs per SIMD lane, allocated in 8s
       (v < 2 ? h->dyn_waves_cu2[v] : h->dyn_roll_waves_cu2[v - 2]) = 4 * std::max(1, std::min(8, 512 / regs));
     }
@@ -2166,7 +2189,7 @@ int mg_rollout(mg_handle* h, int32_t n_steps, const void* actions, const mg_roll
   if (!out->obs_image || !out->reward || !out->dir_done) return fail(MG_EINVAL, "obs_image, reward and dir_done of mg_rollout_out must be set");
   if (h->buf.env_reward) return fail(MG_EUNSUPPORTED, "mg_rollout / mg_rollout_random have no env_reward output (emit_env_reward = 0)");
   if (!h->have_reset) return fail(MG_ESTATE, "mg_reset must be called before mg_rollout / mg_rollout_random");
-  if (h->dynamic && h->dvar->roll[dyn_dec_index(h)] && !debug_env("MG_DEBUG_DYN_ROLL_STEPS")) {
+  if (h->dynamic && h->dyn_roll_fn[dyn_dec_index(h)] && !debug_env("MG_DEBUG_DYN_ROLL_STEPS")) {
     // Mutable-grid kinds: the fused kernel of mg_dyn.h (a chunk's grids stay in LDS over the n_steps steps)
     int rc = launch(h, OP_STEP, actions, nullptr, nullptr, nullptr, nullptr, actions ? 0 : 1, nullptr, nullptr, nullptr, nullptr, n_steps, out);
     if (rc == MG_OK) h->t += (uint64_t)n_steps;
@@ -2373,3 +2396,4 @@ int mg_debug_vis_masks(int V, const uint64_t* patterns, int64_t n, uint64_t* out
 }
 
 }  // extern "C"
+#endif  // MG_TU_DYNROLL

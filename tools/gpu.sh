@@ -37,7 +37,7 @@ case $cmd in
 build)
   name=$1; shift
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Iinclude -Imultigrid_amd/csrc \
-    "$@" -o tools/libmgrid_$name.so multigrid_amd/csrc/mgrid.hip ;;
+    "$@" -o tools/libmgrid_$name.so multigrid_amd/csrc/mgrid.hip multigrid_amd/csrc/mgrid_dynroll.hip ;;
 sweep)
   out=gpurun_out/sweep.txt; sizes=1048576; envs="-"; works=static; libs=multigrid_amd/libmgrid.so; steps=200; rounds=5
   while getopts "o:n:e:w:l:s:r:" o; do case $o in o) out=$OPTARG;; n) sizes=$OPTARG;; e) envs=$OPTARG;; w) works=$OPTARG;; l) libs=$OPTARG;;

@@ -34,10 +34,17 @@ def regs(text):
 
 
 def compile_to_asm(path):
-  cmd = [os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
-         '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'multigrid_amd', 'csrc'), '--cuda-device-only', '-S',
-         '-o', path, os.path.join(ROOT, 'multigrid_amd', 'csrc', 'mgrid.hip')]
-  subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+  """Device ISA of both translation units of libmgrid.so (mgrid.hip, mgrid_dynroll.hip), concatenated into `path`."""
+  parts = []
+  for src in ('mgrid.hip', 'mgrid_dynroll.hip'):
+    part = path + '.' + src + '.s'
+    cmd = [os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
+           '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'multigrid_amd', 'csrc'), '--cuda-device-only', '-S',
+           '-o', part, os.path.join(ROOT, 'multigrid_amd', 'csrc', src)]
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    parts.append(open(part).read())
+  with open(path, 'w') as f:
+    f.write('\n'.join(parts))
 
 
 VMEM = ('global_load', 'global_store', 'global_atomic', 'buffer_', 'flat_', 'scratch_', 'tbuffer_')

@@ -42,6 +42,11 @@ def main():
   torch.cuda.synchronize(dev)
   ms_roll = timed(lambda: env.rollout_random(K, out=traj), args.reps, torch, dev) / K
   ms_single = timed(env.step_random, args.reps * K, torch, dev)
+  # the same fused launch fed from a caller's action ring (mg_rollout) instead of drawing the actions
+  ring = torch.randint(0, 7, (K, env.stride, env.slots), dtype=torch.uint8, device=dev)      # already in the device layout
+  traj2 = env.rollout(ring)
+  torch.cuda.synchronize(dev)
+  ms_ring = timed(lambda: env.rollout(ring, out=traj2), args.reps, torch, dev) / K
   os.environ['MG_DEBUG_DYN_ROLL_STEPS'] = '1'
   env.rollout_random(K, out=traj)
   ms_steps = timed(lambda: env.rollout_random(K, out=traj), args.reps, torch, dev) / K
@@ -54,7 +59,7 @@ def main():
   b_step = obs_b + env.slots + 8.0 * A + env.slots + state_b
   n = args.envs
   print(json.dumps({'lib': args.lib or 'product', 'env_id': args.env_id, 'envs': n, 'K': K, 'us_per_step_fused': ms_roll * 1e3,
-                    'us_per_step_single_step_random': ms_single * 1e3, 'us_per_step_round2_form': ms_steps * 1e3,
+                    'us_per_step_single_step_random': ms_single * 1e3, 'us_per_step_fused_caller_actions': ms_ring * 1e3, 'us_per_step_round2_form': ms_steps * 1e3,
                     'agent_steps_per_s_fused': A * n / (ms_roll * 1e-3), 'bytes_per_env_step_fused': b_roll, 'bytes_per_env_step_single': b_step,
                     'frac_8TBs_fused_own_bytes': b_roll * n / (ms_roll * 1e-3) / 8e12,
                     'frac_8TBs_fused_at_step_bytes': b_step * n / (ms_roll * 1e-3) / 8e12,
