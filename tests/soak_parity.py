@@ -22,7 +22,11 @@ def main():
   ap.add_argument('--ids', default='')
   ap.add_argument('--rollout', type=int, default=0, help='K > 0: take the steps K at a time through the fused rollout launch '
                   '(mg_rollout_random; shared-map and mutable-grid kernels) instead of one launch per step')
+  ap.add_argument('--lib', default=None, help='another build of libmgrid.so (tools/gpu.sh build ...) to check instead of the product')
   args = ap.parse_args()
+  if args.lib:
+    from multigrid_amd import lib
+    lib.LIB_PATH = os.path.abspath(args.lib)
   N, bad = args.envs, 0
   for k, env_id in enumerate(i for i in registry.registered_ids() if args.ids in i):
     t0 = time.time()
