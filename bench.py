@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENV_ID = 'MultiGrid-Cluttered-Fixed-15x15'
+CONFIG4_ID = 'MultiGrid-DoorKey-8x8-v0'       # BASELINE config 4's kind, reported as a side measurement
 B_ALG_PER_ENV_STEP = 308          # algorithmic bytes per env-step (f64 rewards)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ACTION_RING = 16                  # distinct pre-generated action batches cycled through
@@ -158,6 +159,8 @@ def main():
   ap.add_argument('--rollout-envs', type=int, default=131072, help='third, short measurement: the fused K-step rollout launch at this '
                   "many envs per GPU, reported under 'rollout'; 0 = off")
   ap.add_argument('--rollout-k', type=int, default=32)
+  ap.add_argument('--config4-envs', type=int, default=1 << 20, help="fourth, short measurement: BASELINE config 4's DoorKey-8x8 on per-env "
+                  "mutable grids at this many envs per GPU (+ its fused rollout), reported under 'config4'; 0 = off")
   ap.add_argument('--stagger', action='store_true', help='start the 64-env chunks at staggered episode ages, so that every launch '
                   'auto-resets 1/max_steps of the envs (default: lock-step, all envs auto-reset in the same launch)')
   ap.add_argument('--rehearse-cpu', action='store_true', help='launcher rehearsal without a GPU: ranks rendezvous (gloo), '
@@ -208,10 +211,12 @@ def main():
       dist.barrier()
     torch.cuda.synchronize(dev)
 
-  def measure(envs_per_gpu, warmup, steps, long_cycle=False):
+  def measure(envs_per_gpu, warmup, steps, long_cycle=False, env_id=None):
     """W untimed + exactly K timed steps of `envs_per_gpu` envs on this rank; whole-job numbers (max over ranks)."""
+    env_id = env_id or args.env_id
+    headline = env_id == ENV_ID
     base, n = shard.shard_range(rank, world, envs_per_gpu)
-    env = multigrid_amd.make_batched(args.env_id, n, device=local_rank, seed=0xC0FFEE, env_id_base=base,
+    env = multigrid_amd.make_batched(env_id, n, device=local_rank, seed=0xC0FFEE, env_id_base=base,
                                      shaping='v8', auto_reset=True)
     A, V = env.n_agents, env.view_size
     # bytes one env-step has to move (SURVEY §8d): obs + dir/done + f64 rewards + actions + env_state r/w,
@@ -286,11 +291,12 @@ def main():
     env.close()
     return res
 
-  def measure_rollout(envs_per_gpu, K, reps):
+  def measure_rollout(envs_per_gpu, K, reps, env_id=None):
     """The fused K-step launch (mg_rollout_random: on-device random actions, env state in registers, trajectory
     buffers [K][...]) — a different kernel with its own byte count: no action read, env_state traffic once per K steps."""
+    env_id = env_id or args.env_id
     base, n = shard.shard_range(rank, world, envs_per_gpu)
-    env = multigrid_amd.make_batched(args.env_id, n, device=local_rank, seed=0xC0FFEE, env_id_base=base,
+    env = multigrid_amd.make_batched(env_id, n, device=local_rank, seed=0xC0FFEE, env_id_base=base,
                                      shaping='v8', auto_reset=True)
     A, V = env.n_agents, env.view_size
     env.reset()
@@ -311,10 +317,12 @@ def main():
     wall, value = shard.aggregate(dist, wall, float(n) * A * K * reps, world)
     kernel_ms, _ = shard.aggregate(dist, kernel_ms, 0.0, world)
     b_alg = A * V * V * 3 + env._dir_done.shape[1] + 8 * A + env.slots + 2.0 * 4 * (A + 1) / K
+    if env.mutable_grid:      # per-env grids, carry (and aux) are read and written once per launch as well
+      b_alg += (2.0 * env.slots + 8.0 * ((env.width * env.height + 3) // 4) + (32 if env.aux is not None else 0)) / K
     errs = env.check_errors()
     env.close()
-    return {'workload': 'mg_rollout_random: %d fused steps per launch, %d envs per GPU, actions drawn on device (Philox), every '
-                        "step's obs / rewards / dir-done / actions written to [K][...] trajectory buffers" % (K, n),
+    return {'workload': '%s, mg_rollout_random: %d fused steps per launch, %d envs per GPU, actions drawn on device (Philox), every '
+                        "step's obs / rewards / dir-done / actions written to [K][...] trajectory buffers" % (env_id, K, n),
             'value': value, 'unit': 'agent-steps/s', 'env_steps_timed': K * reps, 'kernel_ms_per_step': kernel_ms,
             'alg_bytes_per_env_step': b_alg,
             'roofline_frac': b_alg * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -332,6 +340,17 @@ def main():
   roll = None
   if headline and args.rollout_envs:
     roll = measure_rollout(args.rollout_envs, args.rollout_k, max(1, min(args.steps, 640) // args.rollout_k))
+
+  # BASELINE config 4 (side measurement, never the headline): DoorKey-8x8 x 3 agents on per-env mutable grids — the step kernel
+  # at the headline's batch size and its fused K-step rollout at config 3's per-GPU shard
+  cfg4 = None
+  if headline and args.config4_envs:
+    c4 = measure(args.config4_envs, 50, min(args.steps, 200), env_id=CONFIG4_ID)
+    c4r = measure_rollout(args.rollout_envs or 131072, args.rollout_k, 4, env_id=CONFIG4_ID)
+    cfg4 = {'workload': '%s, %d agents, view %d, per-env mutable grids (mg_dyn_kernel), %d envs per GPU' % (CONFIG4_ID, c4['A'], c4['V'], c4['n']),
+            'value': c4['value'], 'unit': 'agent-steps/s', 'kernel_ms': c4['kernel_ms'], 'alg_bytes_per_env_step': c4['b_alg'],
+            'roofline_frac': c4['b_alg'] * c4['n'] / (c4['kernel_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 'device_errors': c4['errs'],
+            'rollout': c4r}
 
   # who took part: every rank's device, gathered on all ranks; ranks that share a card are an error outside a rehearsal
   mine = device_record(torch, rank, local_rank)
@@ -378,6 +397,8 @@ def main():
                      'roofline_frac': a_ach / HBM_PEAK_GBS, 'launch': also['launch'], 'device_errors': also['errs']}
     if roll is not None:
       out['rollout'] = roll
+    if cfg4 is not None:
+      out['config4'] = cfg4
     if world == 1 and not args.no_cpu_baseline and headline:
       out['cpu_baseline'] = cpu_baseline(m['cells'], args.cpu_seconds)
     sys.stdout.flush()

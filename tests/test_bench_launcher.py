@@ -63,13 +63,14 @@ def test_single_rank_needs_no_launcher():
 
 @pytest.mark.gpu
 def test_two_ranks_on_one_card_real_bench():
-  r = _run(['--gpus', '2', '--backend', 'gloo', '--all-on-device0', '--envs', '8192', '--also-envs', '0', '--rollout-envs', '4096', '--rollout-k', '8', '--steps', '30',
+  r = _run(['--gpus', '2', '--backend', 'gloo', '--all-on-device0', '--envs', '8192', '--also-envs', '0', '--rollout-envs', '4096', '--rollout-k', '8', '--config4-envs', '4096', '--steps', '30',
             '--warmup', '5', '--no-cpu-baseline', '--stagger'])
   assert r.returncode == 0, r.stderr[-3000:]
   d = _one_json_line(r.stdout)
   assert d['n_gpus'] == 2 and d['config']['envs_per_gpu'] == 8192 and d['config']['global_envs'] == 16384
   assert d['device_errors'] == 0 and d['value'] > 0
   assert d['rollout']['device_errors'] == 0 and d['rollout']['env_steps_timed'] == 24 and d['rollout']['value'] > 0
+  assert d['config4']['device_errors'] == 0 and d['config4']['value'] > 0 and d['config4']['rollout']['device_errors'] == 0
   assert 0.0 < d['config']['auto_reset']['env_steps_reset_in_timed_region_frac'] < 0.05
   # two records, both naming the one card (a declared rehearsal: the same PCI bus id is allowed), each with its own kernel time
   assert [r['rank'] for r in d['ranks']] == [0, 1] and d['ranks'][0]['pci_bus_id'] == d['ranks'][1]['pci_bus_id'] is not None

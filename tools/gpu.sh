@@ -54,7 +54,7 @@ bench-sweep)
   while getopts "o:n:" o; do case $o in o) out=$OPTARG;; n) sizes=$OPTARG;; *) exit 2;; esac; done
   shift $((OPTIND - 1)); : > "$out"
   for n in $sizes; do
-    timeout -k 10 150 python bench.py --envs $n --steps 1000 --warmup 100 --no-cpu-baseline --also-envs 0 --rollout-envs 0 "$@" >> "$out" 2>> gpurun_out/sweep.err || exit 1
+    timeout -k 10 150 python bench.py --envs $n --steps 1000 --warmup 100 --no-cpu-baseline --also-envs 0 --rollout-envs 0 --config4-envs 0 "$@" >> "$out" 2>> gpurun_out/sweep.err || exit 1
   done
   python - "$out" <<'PY'
 import json, sys
@@ -66,14 +66,14 @@ PY
 prof)
   out=$1; what=$2; shift 2
   if [ "$what" = kbench ]; then target="$REPO/tools/kbench $REPO/$MAP $1 100 3 $REPO/$2"
-  else target="python3 $REPO/bench.py --steps 500 --warmup 50 --no-cpu-baseline --also-envs 0 --rollout-envs 0 $*"; fi
+  else target="python3 $REPO/bench.py --steps 500 --warmup 50 --no-cpu-baseline --also-envs 0 --rollout-envs 0 --config4-envs 0 $*"; fi
   mkdir -p "$REPO/$out"; cd /tmp && export TMPDIR=/tmp
   timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$out" -- $target > "$REPO/$out/run.log" 2>&1 || { tail -5 "$REPO/$out/run.log"; exit 1; }
   cd "$REPO" && find "$out" -name "*kernel_stats.csv" | while read -r f; do echo "$f"; head -5 "$f" | cut -c1-220; done ;;
 pmc)
   out=$1; what=$2; shift 2
   if [ "$what" = kbench ]; then target=$(kbench_target "$1" "$2")
-  else target="python3 $REPO/bench.py --steps 40 --warmup 10 --no-cpu-baseline --also-envs 0 --rollout-envs 0 $*"; fi
+  else target="python3 $REPO/bench.py --steps 40 --warmup 10 --no-cpu-baseline --also-envs 0 --rollout-envs 0 --config4-envs 0 $*"; fi
   rocprof_passes "$out" $target <<'P'
 sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
