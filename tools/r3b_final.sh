@@ -35,10 +35,11 @@ for l in open('gpurun_out/r3b_dyn_roll_final.jsonl'):
 PY
   ;;
 c)
-  timeout -k 10 900 python -u tests/soak_parity.py --envs 60000 --steps 1536 --rollout 64 --seed 27183 --max-steps 100 2>&1 | grep -v amdgpu.ids > gpurun_out/r3b_soak_rollout_60000.txt || { tail -5 gpurun_out/r3b_soak_rollout_60000.txt; exit 1; }
+  timeout -k 10 900 python -u tests/soak_parity.py --envs 60000 --steps 1536 --rollout 64 --seed 27183 --max-steps 100 > gpurun_out/r3b_soak_rollout_60000.txt 2>&1 || { tail -5 gpurun_out/r3b_soak_rollout_60000.txt; exit 1; }
   tail -2 gpurun_out/r3b_soak_rollout_60000.txt
+  : > gpurun_out/r3b_soak_rollout_1M.txt
   for spec in "Cluttered-Fixed-15x15 1048576 128 100" "DoorKey-8x8-v0 1000000 64 60" "Cluttered-v0 1000000 64 60" "Meetup-Random-8x8-v0 1000000 64 60"; do set -- $spec
-    timeout -k 10 400 python -u tests/soak_parity.py --ids $1 --envs $2 --steps $3 --rollout 32 --seed 161 --max-steps $4 2>&1 | grep -v amdgpu.ids >> gpurun_out/r3b_soak_rollout_1M.txt || { tail -5 gpurun_out/r3b_soak_rollout_1M.txt; exit 1; }
+    timeout -k 10 400 python -u tests/soak_parity.py --ids $1 --envs $2 --steps $3 --rollout 32 --seed 161 --max-steps $4 >> gpurun_out/r3b_soak_rollout_1M.txt 2>&1 || { tail -5 gpurun_out/r3b_soak_rollout_1M.txt; exit 1; }
   done
   cat gpurun_out/r3b_soak_rollout_1M.txt
   ;;
