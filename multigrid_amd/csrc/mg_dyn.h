@@ -938,8 +938,24 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   }
 }
 
-template <int A, int V, bool FULL, int PRE, bool DEC>
-__global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p) {   // up to 8 waves per workgroup (dyn_geometry)
+// FREE (round 3, second half) = the free-running step as an instantiation of its own: a launch with no injected draws, no reset
+// mask and no env_reward output — every mg_step / mg_step_random of a handle created without emit_env_reward — has those
+// switches as compile-time constants, so their branches and the scalar registers that carried the pointers go.  The general
+// instantiation keeps running resets, replay and env_reward handles.  (These kernels live in mgrid_dynroll.hip's code object.)
+template <bool FREE>
+__device__ __forceinline__ Params dyn_params(const Params& p0) {
+  if constexpr (!FREE) return p0;
+  else {
+    Params q = p0;
+    q.op = OP_STEP; q.order = nullptr; q.respawn = nullptr; q.reset_spawn = nullptr; q.objdrop = nullptr; q.reset_gen = nullptr;
+    q.scatter = nullptr; q.mask = nullptr; q.env_reward = nullptr;
+    return q;
+  }
+}
+
+template <int A, int V, bool FULL, int PRE, bool DEC, bool FREE = false>
+__global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p0) {   // up to 8 waves per workgroup (dyn_geometry)
+  const Params p = dyn_params<FREE>(p0);
   constexpr int ROWB = ViewGeom<V>::ROWB;
   // (The ~85 dwords of Params do not fit the 102 SGPRs next to the loop's own uniform values: the compiler spills ~350
   //  of them to VGPR lanes and reads whole 16-dword kernarg tuples back, ~700 v_readlane per chunk.  Holding the eight
@@ -1066,7 +1082,10 @@ __global__ __launch_bounds__(512, FULL ? MG_DYN_ROLL_FULL_WAVES : 1) void mg_dyn
   const int64_t slot_obs = FULL ? p.stride * (int64_t)(cells * 3) : (int64_t)A * p.stride * ROWB;
   const int64_t slot_rew = (int64_t)A * p.stride * (p.reward_f32 ? 4 : 8);
   const int64_t slot_dd = p.stride * p.dd_bytes, slot_act = p.stride * kSlotWords<A>;
-  Params q = p;
+  // what a rollout launch never has (launch() passes none of it) as compile-time constants, as in the FREE step kernel: the
+  // injection paths, the reset mask and the env_reward output fold away, and with them the scalar registers that carried
+  // their pointers (DoorKey-8x8 16.4 -> 15.6 us per step at 131072 envs, Cluttered-15x15 17.2 -> 16.4)
+  Params q = dyn_params<true>(p);
   for (int64_t c = (int64_t)blockIdx.x * nw + wv; c < p.n_chunks; c += cstride) {
     DynIn<A, PRE> cur = {};
     dyn_load<A, PRE>(p, c * kWave, lane, cur);

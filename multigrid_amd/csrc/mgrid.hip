@@ -1064,20 +1064,23 @@ __global__ __launch_bounds__(kMaxBlock) void mg_rollout_kernel(const Params p) {
 
 #ifdef MG_TU_DYNROLL
 // ---- second translation unit (mgrid_dynroll.hip): nothing but the fused mutable-grid rollout kernels and their lookup ----
-struct DynRollEntry { int A, V; bool full; int pre; const void* fn[2]; };
+struct DynRollEntry { int A, V; bool full; int pre; const void* fn[2]; const void* step_free[2]; };
 #define MG_DYN_ROLL(A, V, FULL, PRE) {A, FULL ? 0 : V, FULL, PRE, {(const void*)mg_dyn_rollout_kernel<A, V, FULL, PRE, false>, \
-                                      FULL ? (const void*)nullptr : (const void*)mg_dyn_rollout_kernel<A, V, FULL, PRE, !FULL>}},
+                                      FULL ? (const void*)nullptr : (const void*)mg_dyn_rollout_kernel<A, V, FULL, PRE, !FULL>}, \
+                                      {(const void*)mg_dyn_kernel<A, V, FULL, PRE, false, true>, \
+                                      FULL ? (const void*)nullptr : (const void*)mg_dyn_kernel<A, V, FULL, PRE, !FULL, true>}},
 const DynRollEntry kDynRoll[] = { MG_DYN_LIST(MG_DYN_ROLL) };
 }  // namespace
 
-extern "C" __attribute__((visibility("hidden"))) const void* mg_dynroll_kernel(int A, int V, int full, int pre, int dec) {
+// which: 0 = the fused rollout kernel, 1 = the free-running step kernel (mg_dyn_kernel<..., FREE>)
+extern "C" __attribute__((visibility("hidden"))) const void* mg_dynroll_kernel(int A, int V, int full, int pre, int dec, int which) {
   for (const DynRollEntry& e : kDynRoll)
-    if (e.A == A && e.V == V && e.full == (full != 0) && e.pre == pre) return e.fn[dec ? 1 : 0];
+    if (e.A == A && e.V == V && e.full == (full != 0) && e.pre == pre) return (which ? e.step_free : e.fn)[dec ? 1 : 0];
   return nullptr;
 }
 #else
 // (defined in mgrid_dynroll.hip's translation unit; C linkage, hidden: not part of the library's ABI)
-extern "C" __attribute__((visibility("hidden"))) const void* mg_dynroll_kernel(int A, int V, int full, int pre, int dec);
+extern "C" __attribute__((visibility("hidden"))) const void* mg_dynroll_kernel(int A, int V, int full, int pre, int dec, int which);
 
 // ---------------------------------------------------------------------------------------------
 // mg_step_noalloc: the per-GPU scratch its kernels use instead of a handle's hipMalloc'ed tables.
@@ -1350,6 +1353,8 @@ struct mg_handle {
   int dyn_waves_cu2[2];  // waves of the mutable-grid kernel (table-decoding / arithmetic) a CU can hold by registers
   int dyn_roll_waves_cu2[2];   // the same for the fused rollout kernels
   const void* dyn_roll_fn[2];  // those kernels (mgrid_dynroll.hip's code object), null where there is none
+  const void* dyn_free_fn[2];  // mg_dyn_kernel<..., FREE>: the free-running step (same code object)
+  int dyn_free_waves_cu2[2];
   bool dyn_dec;          // this layout family's views decode their cell codes arithmetically (DEC, mg_dyn.h)
   int fixed_mode; uint64_t fixed_pd; uint32_t fixed_pd_hi;       // mg_set_fixed_spawn
   std::vector<uint8_t> free_cells;         // host copy: cell (y*W + x) holds nothing (placement checks)
@@ -1457,7 +1462,7 @@ int dyn_dec_index(const mg_handle* h) {
 
 // Mutable-grid launch geometry: 4 waves per workgroup (fewer for small batches), as many workgroups
 // per CU as LDS allows; persistent over chunks.
-void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* lds_out, bool roll = false) {
+void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* lds_out, int which = 0) {   // which: 0 general step, 1 rollout, 2 free step
   const mg_config& c = h->cfg;
   const size_t rowb = h->full_obs ? 0 : (size_t)c.view_size * c.view_size * 3;   // fully observed images are not staged
   const size_t fixed = ((size_t)h->LW * h->LH * 8 + (size_t)c.width * c.height * 4 + 256 * 4 + (size_t)h->GW * 4 + 8 + 15) / 16 * 16;
@@ -1466,7 +1471,7 @@ void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* l
   // (queried from the code object at mg_create: 512 VGPRs per SIMD lane / the kernel's count, x 4 SIMDs), and
   // whatever fits 160 KB of LDS.  Ties go to the smaller workgroup; small batches shrink it further so that
   // every CU gets work.
-  const int kDynWavesPerCU = (roll ? h->dyn_roll_waves_cu2 : h->dyn_waves_cu2)[dyn_dec_index(h)];
+  const int kDynWavesPerCU = (which == 1 ? h->dyn_roll_waves_cu2 : which == 2 ? h->dyn_free_waves_cu2 : h->dyn_waves_cu2)[dyn_dec_index(h)];
   int nw = 1, best = 0;
   for (int cand = 1; cand <= 8; ++cand) {
     const size_t need = fixed + cand * per_wave;
@@ -1559,10 +1564,18 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
       p.traj_actions = actions ? nullptr : reinterpret_cast<uint32_t*>(roll->actions);
       p.nt_obs = 0xFF;
       if (const char* e = debug_env("MG_DEBUG_NT")) p.nt_obs = atoi(e);   // tuning experiments only
-      dyn_geometry(h, &nw, &grid, &lds, true);
+      dyn_geometry(h, &nw, &grid, &lds, 1);
       void* kargs[] = {&p};
       HIP_TRY(hipLaunchKernel(h->dyn_roll_fn[dyn_dec_index(h)], dim3(grid), dim3(nw * kWave), kargs, lds, h->stream));
       return launch_ep_stats(h, op, mask, n_roll, roll);
+    }
+    // the free-running step — no injected draws, no mask, no env_reward output — runs its own instantiation (mg_dyn.h FREE)
+    const void* free_fn = h->dyn_free_fn[dyn_dec_index(h)];
+    if (free_fn && op == OP_STEP && !order && !respawn && !reset_spawn && !objdrop && !reset_gen && !scatter && !mask && !h->buf.env_reward) {
+      dyn_geometry(h, &nw, &grid, &lds, 2);
+      void* kargs[] = {&p};
+      HIP_TRY(hipLaunchKernel(free_fn, dim3(grid), dim3(nw * kWave), kargs, lds, h->stream));
+      return dest ? launch_ep_stats(h, op, mask, 1, dest) : launch_ep_stats(h, op, mask, 0, nullptr);
     }
     dyn_geometry(h, &nw, &grid, &lds);
     hipLaunchKernelGGL(h->dvar->fn[dyn_dec_index(h)], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
@@ -1717,13 +1730,18 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   h->ep_on = false; h->ep_thr = 0.0; memset(&h->ep, 0, sizeof(h->ep));
   h->dyn_waves_cu2[0] = h->dyn_waves_cu2[1] = 8; h->dyn_dec = false; h->fixed_mode = 0; h->fixed_pd = 0; h->fixed_pd_hi = 0;
   h->dyn_roll_waves_cu2[0] = h->dyn_roll_waves_cu2[1] = 8;
-  for (int v = 0; v < 2; ++v) h->dyn_roll_fn[v] = dvar ? mg_dynroll_kernel(dvar->A, dvar->V, dvar->full ? 1 : 0, dvar->pre, v) : nullptr;
-  for (int v = 0; dvar && v < 4; ++v) {
+  h->dyn_free_waves_cu2[0] = h->dyn_free_waves_cu2[1] = 8;
+  for (int v = 0; v < 2; ++v) {
+    h->dyn_roll_fn[v] = dvar ? mg_dynroll_kernel(dvar->A, dvar->V, dvar->full ? 1 : 0, dvar->pre, v, 0) : nullptr;
+    h->dyn_free_fn[v] = dvar ? mg_dynroll_kernel(dvar->A, dvar->V, dvar->full ? 1 : 0, dvar->pre, v, 1) : nullptr;
+  }
+  if (debug_env("MG_DEBUG_DYN_NO_FREE")) h->dyn_free_fn[0] = h->dyn_free_fn[1] = nullptr;     // tests / A-B timing: the general step kernel
+  for (int v = 0; dvar && v < 6; ++v) {
     hipFuncAttributes fa;
-    const void* fn = v < 2 ? reinterpret_cast<const void*>(dvar->fn[v]) : h->dyn_roll_fn[v - 2];
+    const void* fn = v < 2 ? reinterpret_cast<const void*>(dvar->fn[v]) : v < 4 ? h->dyn_roll_fn[v - 2] : h->dyn_free_fn[v - 4];
     if (fn && hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.numRegs > 0) {
       const int regs = (fa.numRegs + 7) / 8 * 8;                  // gfx950: 512 VGPRs per SIMD lane, allocated in 8s
-      (v < 2 ? h->dyn_waves_cu2[v] : h->dyn_roll_waves_cu2[v - 2]) = 4 * std::max(1, std::min(8, 512 / regs));
+      (v < 2 ? h->dyn_waves_cu2[v] : v < 4 ? h->dyn_roll_waves_cu2[v - 2] : h->dyn_free_waves_cu2[v - 4]) = 4 * std::max(1, std::min(8, 512 / regs));
     }
   }
   // DoorKey's door row rides in five bits of the state word (mg_dyn.h): grids up to 33 rows; Cluttered / FourRooms

@@ -22,6 +22,8 @@ def main():
   ap.add_argument('--ids', default='')
   ap.add_argument('--rollout', type=int, default=0, help='K > 0: take the steps K at a time through the fused rollout launch '
                   '(mg_rollout_random; shared-map and mutable-grid kernels) instead of one launch per step')
+  ap.add_argument('--no-env-reward', action='store_true', help='handles without the env_reward output: their steps run the free-running '
+                  'instantiations (FAST shared-map kernel, FREE mutable-grid kernel); env rewards are then not compared')
   ap.add_argument('--lib', default=None, help='another build of libmgrid.so (tools/gpu.sh build ...) to check instead of the product')
   args = ap.parse_args()
   if args.lib:
@@ -33,7 +35,7 @@ def main():
     spec = registry.spec(env_id)
     seed = args.seed + k
     ms = min(spec['max_steps'], args.max_steps)
-    env = registry.make_batched(env_id, N, seed=seed, emit_env_reward=not args.rollout, max_steps=ms)
+    env = registry.make_batched(env_id, N, seed=seed, emit_env_reward=not (args.rollout or args.no_env_reward), max_steps=ms)
     spec['max_steps'] = ms
     size = spec.get('size')
     cells = env.cells if spec.get('kind', 'static') == 'static' else None
@@ -67,7 +69,7 @@ def main():
       ref = orc.obs_image[0, :N] if env.obs_full is not None else orc.obs_image[:, :N]
       ok = (np.array_equal(img, ref) and np.array_equal(env.obs_dir.cpu().numpy(), orc.obs_dir[:, :N])
             and np.array_equal(env.reward.cpu().numpy().view(np.int64), orc.reward[:, :N].view(np.int64))
-            and np.array_equal(env.env_reward.cpu().numpy().view(np.int64), orc.env_reward[:, :N].view(np.int64))
+            and (args.no_env_reward or np.array_equal(env.env_reward.cpu().numpy().view(np.int64), orc.env_reward[:, :N].view(np.int64)))
             and np.array_equal(env.done.cpu().numpy(), orc.done[:N]))
       if not ok:
         first = t

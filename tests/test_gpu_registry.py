@@ -55,6 +55,56 @@ def test_registered_id_matches_the_oracle(env_id):
   env.close()
 
 
+def _mutable_ids():
+  return [i for i in registry.registered_ids() if registry.spec(i).get('kind', 'static') != 'static']
+
+
+@pytest.mark.parametrize('env_id', _mutable_ids())
+def test_free_running_instantiation_of_the_mutable_grid_kernel(monkeypatch, env_id):
+  """Handles without the env_reward output step through mg_dyn_kernel<..., FREE> (injection paths, reset mask and env_reward folded
+  at compile time; mgrid_dynroll.hip's code object): every mutable-grid id against the oracle, drawn actions and actions from HBM
+  in turn, and against a twin handle forced onto the general instantiation (MG_DEBUG_DYN_NO_FREE), state and grids included."""
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  spec = registry.spec(env_id)
+  seed = 7 + sum(map(ord, env_id)) % 1000
+  ms = min(spec['max_steps'], 20)
+  env = registry.make_batched(env_id, N, seed=seed, max_steps=ms)                 # no env_reward: the FREE instantiation
+  monkeypatch.setenv('MG_DEBUG_DYN_NO_FREE', '1')
+  twin = registry.make_batched(env_id, N, seed=seed, max_steps=ms)                # read at mg_create: the general one
+  monkeypatch.delenv('MG_DEBUG_DYN_NO_FREE')
+  spec['max_steps'] = ms
+  orc = _oracle_for(spec, None, seed)
+  env.reset(); twin.reset(); orc.reset()
+  A = spec['n_agents']
+  g = torch.Generator(device='cpu').manual_seed(seed)
+  for t in range(50):
+    what = '%s step %d' % (env_id, t)
+    if t % 2:
+      act = torch.randint(0, 7, (A, N), dtype=torch.uint8, generator=g)
+      env.step(act.to(env.device)); twin.step(act.to(twin.device))
+      pad = np.full((A, orc.stride), 6, np.uint8)
+      pad[:, :N] = act.numpy()
+      orc.step(pad)
+    else:
+      env.step_random(); twin.step_random(); orc.step()
+    if env.obs_full is not None:
+      assert np.array_equal(env.obs_full.cpu().numpy().reshape(N, -1), orc.obs_image[0, :N]), what
+      assert torch.equal(env.obs_full, twin.obs_full), what
+    else:
+      assert np.array_equal(env.obs_image.cpu().numpy().reshape(A, N, -1), orc.obs_image[:, :N]), what
+      assert torch.equal(env.obs_image, twin.obs_image), what
+    assert np.array_equal(env.reward.cpu().numpy().view(np.int64), orc.reward[:, :N].view(np.int64)), what
+    assert np.array_equal(env.done.cpu().numpy(), orc.done[:N]) and np.array_equal(env.obs_dir.cpu().numpy(), orc.obs_dir[:, :N]), what
+    assert torch.equal(env.reward.view(torch.int64), twin.reward.view(torch.int64)) and torch.equal(env.done, twin.done), what
+  carry, kinds = orc.dyn_state()
+  assert np.array_equal(env.agent_state.cpu().numpy().view(np.uint32), orc.agent_state()[:, :N])
+  assert np.array_equal(env.grid_kinds().cpu().numpy(), kinds[:N]) and np.array_equal(env.carry.cpu().numpy().view(np.uint32), carry[:N])
+  assert torch.equal(env.grid_kinds(), twin.grid_kinds()) and torch.equal(env.carry, twin.carry) and torch.equal(env._env_state[:N], twin._env_state[:N])
+  assert env.check_errors() == 0 and twin.check_errors() == 0 and orc.errors() == 0
+  env.close(); twin.close()
+
+
 @pytest.mark.parametrize('env_id', ['MultiGrid-Cluttered5-Minigrid-v0', 'MultiGrid-Empty-Random-6x6-Minigrid-v0',
                                     'MultiGrid-MiniFourRooms-Minigrid-v0'])
 def test_minigrid_mode_container_shapes(env_id):

@@ -265,6 +265,34 @@ def test_fused_rollout_on_mutable_grids_matches_the_oracle(monkeypatch, env_id, 
   env.close()
 
 
+@pytest.mark.parametrize('env_id,n', [('MultiGrid-DoorKey-6x6-v0', 1), ('MultiGrid-Meetup-Empty-6x6-v0', 1), ('MultiGrid-Cluttered-v0', 65)])
+def test_fused_rollout_on_mutable_grids_smallest_shapes(env_id, n):
+  """One env, one step per launch, many launches in a row — and one long launch across several auto-resets — against the oracle:
+  the fused kernel's first step and last step are the same step, and its state round trip through HBM happens every call."""
+  _need_gpu()
+  from multigrid_amd import registry
+  spec = registry.spec(env_id)
+  spec['max_steps'] = 12
+  env = registry.make_batched(env_id, n, seed=77, max_steps=12)
+  orc = _dyn_oracle(spec, n, 77)
+  env.reset(); orc.reset()
+  A, full = spec['n_agents'], env.obs_full is not None
+  traj = None
+  for K in [1] * 30 + [70]:
+    traj = env.rollout_random(K, out=traj)
+    img = traj['image'].cpu().numpy().reshape((K, n, -1) if full else (K, A, n, -1))
+    rew, done = traj['reward'].cpu().numpy(), traj['done'].cpu().numpy()
+    for k in range(K):
+      orc.step(None)
+      assert np.array_equal(img[k], orc.obs_image[0, :n] if full else orc.obs_image[:, :n]), (env_id, K, k)
+      assert np.array_equal(rew[k].view(np.int64), orc.reward[:, :n].view(np.int64)) and np.array_equal(done[k], orc.done[:n]), (env_id, K, k)
+    carry, kinds = orc.dyn_state()
+    assert np.array_equal(env.agent_state.cpu().numpy().view(np.uint32), orc.agent_state()[:, :n])
+    assert np.array_equal(env.grid_kinds().cpu().numpy(), kinds[:n]) and np.array_equal(env.carry.cpu().numpy().view(np.uint32), carry[:n])
+  assert env.step_index == 100 and env.check_errors() == 0 and orc.errors() == 0
+  env.close()
+
+
 def test_fused_rollout_on_per_env_maps_and_the_step_by_step_form(monkeypatch):
   """Per-env layouts (mg_set_maps: table decode, per-env reset templates and shaper goals) through the fused kernel against the
   oracle holding the same layouts — drawn actions, then a caller's action ring — and the round-2 form of the same calls

@@ -35,13 +35,17 @@ def regs(text):
 
 def compile_to_asm(path):
   """Device ISA of both translation units of libmgrid.so (mgrid.hip, mgrid_dynroll.hip), concatenated into `path`."""
-  parts = []
-  for src in ('mgrid.hip', 'mgrid_dynroll.hip'):
+  procs = []
+  for src in ('mgrid.hip', 'mgrid_dynroll.hip'):          # side by side: each takes minutes
     part = path + '.' + src + '.s'
     cmd = [os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
            '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'multigrid_amd', 'csrc'), '--cuda-device-only', '-S',
            '-o', part, os.path.join(ROOT, 'multigrid_amd', 'csrc', src)]
-    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    procs.append((part, cmd, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
+  parts = []
+  for part, cmd, pr in procs:
+    if pr.wait() != 0:
+      raise subprocess.CalledProcessError(pr.returncode, cmd)
     parts.append(open(part).read())
   with open(path, 'w') as f:
     f.write('\n'.join(parts))
