@@ -938,6 +938,39 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   }
 }
 
+// The LDS of a mutable-grid workgroup, carved and filled (both kernels): [stage: nw x 64*ROWB B][grids: nw x (W+2)(H+2)*68 B]
+// [distance LUT: LW*LH f64][kind LUT: 256 u32][base: GW u32][pidx: W*H u16][cpc: W*H u16].  Ends with the workgroup barrier.
+struct DynLds {
+  uint32_t* stage_all; uint32_t* grids; double* dist; uint32_t* lut; uint32_t* base;
+  uint16_t* pidx;      // padded cell index of cell y*W + x
+  uint16_t* cpc;       // padded cell index of cell x*H + y (encode() order)
+  int stage_b, pcells;
+};
+__device__ __forceinline__ DynLds dyn_lds_init(const Params& p, uint8_t* smem, int stage_b) {
+  DynLds L;
+  const int nw = blockDim.x >> 6, tid = threadIdx.x;
+  const int pcells = (p.W + 2) * (p.H + 2), cells = p.W * p.H;
+  L.stage_b = stage_b; L.pcells = pcells;     // stage_b per wave; fully observed images are gathered without staging (0)
+  L.stage_all = reinterpret_cast<uint32_t*>(smem);
+  L.grids = reinterpret_cast<uint32_t*>(smem + (size_t)nw * stage_b);
+  L.dist = reinterpret_cast<double*>(L.grids + (size_t)nw * pcells * kCellW + ((nw * pcells * kCellW) & 1));
+  L.lut = reinterpret_cast<uint32_t*>(L.dist + p.LW * p.LH);
+  L.base = L.lut + 256;
+  L.pidx = reinterpret_cast<uint16_t*>(L.base + p.GW);
+  L.cpc = L.pidx + cells;
+  for (int i = tid; i < 256; i += blockDim.x) L.lut[i] = kind_word((uint32_t)i);
+  for (int i = tid; i < p.GW; i += blockDim.x) L.base[i] = p.base_grid[i];
+  for (int i = tid; i < p.LW * p.LH; i += blockDim.x) L.dist[i] = p.dist_lut[i];
+  for (int i = tid; i < cells; i += blockDim.x) {
+    L.pidx[i] = (uint16_t)((i / p.W + 1) * (p.W + 2) + (i % p.W) + 1);
+    L.cpc[i] = (uint16_t)((i % p.H + 1) * (p.W + 2) + (i / p.H) + 1);
+  }
+  // every wave's padded grid starts as all grey wall: the ring is never written again
+  for (int i = tid; i < nw * pcells * kCellW; i += blockDim.x) L.grids[i] = K_WALL * 0x01010101u;
+  __syncthreads();
+  return L;
+}
+
 // FREE (round 3, second half) = the free-running step as an instantiation of its own: a launch with no injected draws, no reset
 // mask and no env_reward output — every mg_step / mg_step_random of a handle created without emit_env_reward — has those
 // switches as compile-time constants, so their branches and the scalar registers that carried the pointers go.  The general
@@ -953,6 +986,8 @@ __device__ __forceinline__ Params dyn_params(const Params& p0) {
   }
 }
 
+// (Fully observed FREE kernels need 148 VGPRs; forced to 128 for a fourth wave per SIMD — 10 spilled registers, lint clean with
+//  16 prefetched rows — Meetup-8x8 ran 107.8 -> 111.0 us at 1M envs and 30.5 -> 33.6 at 131072: three waves stay.)
 template <int A, int V, bool FULL, int PRE, bool DEC, bool FREE = false>
 __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p0) {   // up to 8 waves per workgroup (dyn_geometry)
   const Params p = dyn_params<FREE>(p0);
@@ -962,18 +997,7 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p0) {   // up 
   //  per-chunk pointers in vector registers instead removed a quarter of those and made DoorKey-8x8 5 % SLOWER
   //  (138 -> 144 us, round 3), so the spills stay.)
   extern __shared__ __align__(16) uint8_t smem[];
-  // LDS carve: [stage: nw x 64*ROWB B][grids: nw x (W+2)(H+2)*68 B][distance LUT: LW*LH f64][kind LUT: 256 u32]
-  //            [base: GW u32][pidx: W*H u16][cpc: W*H u16]
   const int nw = blockDim.x >> 6;
-  const int pcells = (p.W + 2) * (p.H + 2), cells = p.W * p.H;
-  uint32_t* stage_all = reinterpret_cast<uint32_t*>(smem);
-  const int stage_b = FULL ? 0 : kWave * ROWB;    // per wave; fully observed images are gathered without staging
-  uint32_t* grids = reinterpret_cast<uint32_t*>(smem + (size_t)nw * stage_b);
-  double* dist = reinterpret_cast<double*>(grids + (size_t)nw * pcells * kCellW + ((nw * pcells * kCellW) & 1));
-  uint32_t* lut = reinterpret_cast<uint32_t*>(dist + p.LW * p.LH);
-  uint32_t* base = lut + 256;
-  uint16_t* pidx = reinterpret_cast<uint16_t*>(base + p.GW);   // padded cell index of cell y*W + x
-  uint16_t* cpc = pidx + cells;                                // padded cell index of cell x*H + y (encode() order)
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
 
   // persistent: each wave strides over the 64-env chunks; the first chunk's inputs are requested
@@ -983,19 +1007,13 @@ __global__ __launch_bounds__(512) void mg_dyn_kernel(const Params p0) {   // up 
   DynIn<A, PRE> cur = {}, nxt;
   if (c < p.n_chunks) dyn_load<A, PRE>(p, c * kWave, lane, cur);
 
-  for (int i = tid; i < 256; i += blockDim.x) lut[i] = kind_word((uint32_t)i);
-  for (int i = tid; i < p.GW; i += blockDim.x) base[i] = p.base_grid[i];
-  for (int i = tid; i < p.LW * p.LH; i += blockDim.x) dist[i] = p.dist_lut[i];
-  for (int i = tid; i < cells; i += blockDim.x) {
-    pidx[i] = (uint16_t)((i / p.W + 1) * (p.W + 2) + (i % p.W) + 1);
-    cpc[i] = (uint16_t)((i % p.H + 1) * (p.W + 2) + (i / p.H) + 1);
-  }
-  // every wave's padded grid starts as all grey wall: the ring is never written again
-  for (int i = tid; i < nw * pcells * kCellW; i += blockDim.x) grids[i] = K_WALL * 0x01010101u;
-  __syncthreads();
+  const DynLds L = dyn_lds_init(p, smem, FULL ? 0 : kWave * ROWB);
+  const double* dist = L.dist;
+  const uint32_t* lut = L.lut; const uint32_t* base = L.base;
+  const uint16_t* pidx = L.pidx; const uint16_t* cpc = L.cpc;
 
-  uint32_t* stage = stage_all + wv * (stage_b / 4);
-  uint32_t* gw = grids + (size_t)wv * pcells * kCellW;
+  uint32_t* stage = L.stage_all + wv * (L.stage_b / 4);
+  uint32_t* gw = L.grids + (size_t)wv * L.pcells * kCellW;
   uint32_t err = 0;
   // vector-memory operations a chunk issues after the next chunk's prefetch, all of them for at least one lane.
   // Partial views: the obs stores (the request is issued right before them, dyn_chunk).  Fully observed: the request is
@@ -1053,30 +1071,15 @@ template <int A, int V, bool FULL, int PRE, bool DEC>
 __global__ __launch_bounds__(512, FULL ? MG_DYN_ROLL_FULL_WAVES : 1) void mg_dyn_rollout_kernel(const Params p) {   // fully observed: three waves per SIMD, like their step kernels
   constexpr int ROWB = ViewGeom<V>::ROWB;
   extern __shared__ __align__(16) uint8_t smem[];
-  // the LDS carve of mg_dyn_kernel
-  const int nw = blockDim.x >> 6;
-  const int pcells = (p.W + 2) * (p.H + 2), cells = p.W * p.H;
-  uint32_t* stage_all = reinterpret_cast<uint32_t*>(smem);
-  const int stage_b = FULL ? 0 : kWave * ROWB;
-  uint32_t* grids = reinterpret_cast<uint32_t*>(smem + (size_t)nw * stage_b);
-  double* dist = reinterpret_cast<double*>(grids + (size_t)nw * pcells * kCellW + ((nw * pcells * kCellW) & 1));
-  uint32_t* lut = reinterpret_cast<uint32_t*>(dist + p.LW * p.LH);
-  uint32_t* base = lut + 256;
-  uint16_t* pidx = reinterpret_cast<uint16_t*>(base + p.GW);
-  uint16_t* cpc = pidx + cells;
+  const int nw = blockDim.x >> 6, cells = p.W * p.H;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
-  for (int i = tid; i < 256; i += blockDim.x) lut[i] = kind_word((uint32_t)i);
-  for (int i = tid; i < p.GW; i += blockDim.x) base[i] = p.base_grid[i];
-  for (int i = tid; i < p.LW * p.LH; i += blockDim.x) dist[i] = p.dist_lut[i];
-  for (int i = tid; i < cells; i += blockDim.x) {
-    pidx[i] = (uint16_t)((i / p.W + 1) * (p.W + 2) + (i % p.W) + 1);
-    cpc[i] = (uint16_t)((i % p.H + 1) * (p.W + 2) + (i / p.H) + 1);
-  }
-  for (int i = tid; i < nw * pcells * kCellW; i += blockDim.x) grids[i] = K_WALL * 0x01010101u;
-  __syncthreads();
+  const DynLds L = dyn_lds_init(p, smem, FULL ? 0 : kWave * ROWB);
+  const double* dist = L.dist;
+  const uint32_t* lut = L.lut; const uint32_t* base = L.base;
+  const uint16_t* pidx = L.pidx; const uint16_t* cpc = L.cpc;
 
-  uint32_t* stage = stage_all + wv * (stage_b / 4);
-  uint32_t* gw = grids + (size_t)wv * pcells * kCellW;
+  uint32_t* stage = L.stage_all + wv * (L.stage_b / 4);
+  uint32_t* gw = L.grids + (size_t)wv * L.pcells * kCellW;
   uint32_t err = 0;
   const int64_t cstride = (int64_t)gridDim.x * nw;
   const int64_t slot_obs = FULL ? p.stride * (int64_t)(cells * 3) : (int64_t)A * p.stride * ROWB;

@@ -2344,7 +2344,8 @@ int mg_get_goal(mg_handle* h, int32_t* gx, int32_t* gy) {
 int mg_get_launch_info(mg_handle* h, int32_t* path, int32_t* block_threads, int32_t* grid_blocks, int32_t* lds_bytes) {
   if (!h) return fail(MG_EINVAL, "null handle");
   int nw; unsigned grid; size_t lds;
-  if (h->dynamic) dyn_geometry(h, &nw, &grid, &lds);
+  // the geometry of a plain mg_step launch: on a mutable-grid handle without the env_reward output that is the FREE instantiation
+  if (h->dynamic) dyn_geometry(h, &nw, &grid, &lds, (h->dyn_free_fn[dyn_dec_index(h)] && !h->buf.env_reward) ? 2 : 0);
   else launch_geometry(h, launch_uses_table(h), &nw, &grid, &lds);
   if (path) *path = launch_uses_table(h) ? MG_PATH_TABLE : MG_PATH_GENERIC;
   if (block_threads) *block_threads = nw * kWave;
