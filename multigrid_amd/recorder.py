@@ -40,6 +40,11 @@ Fixture schema (E episodes, T = longest episode, A agents, V view size):
   done          uint8[E, T]
   agent_pos     uint8[E, T+1, A, 2], agent_dir uint8[E, T+1, A], carry uint8[E, T+1, A] (kind ids)
 Steps past an episode's length are zero padding.
+Digest form (`strip_to_digest`, `record --digest`): the input arrays above (meta … objdrop) and, in place of the expected ones,
+  digest        uint64[E, 2]              one 128-bit checksum per episode of obs_image / obs_dir / env_reward / shaped_reward / done /
+                                          agent_pos / agent_dir (/ carry) at every step, in replay order (EpisodeDigest)
+  shaped, has_carry, touches               what the full recording held (shaped rewards? carried kinds? how many rewarded steps)
+`replay_on_device` and the oracle replays of the tests take either form.
 """
 import json
 from unittest import mock
@@ -515,14 +520,16 @@ def main(argv=None):
   r.add_argument('--seed', type=int, default=0)
   r.add_argument('--shaping', default='v8', choices=['v8', 'v7', 'none'])
   r.add_argument('--out', required=True)
+  r.add_argument('--digest', action='store_true', help='keep the inputs and one 128-bit checksum per episode instead of the expected '
+                 'arrays (strip_to_digest): the form for recordings of thousands of episodes')
   p = sub.add_parser('replay', help='replay a fixture on the GPU and compare bit for bit')
   p.add_argument('fixture')
   p.add_argument('--device', type=int, default=0)
   a = ap.parse_args(argv)
   if a.cmd == 'record':
     rec = record_reference(a.reference, a.env_id, a.episodes, a.seed, None if a.shaping == 'none' else a.shaping)
-    save(a.out, rec)
-    print('recorded %d episodes -> %s' % (len(rec['length']), a.out))
+    save(a.out, strip_to_digest(rec) if a.digest else rec)
+    print('recorded %d episodes -> %s%s' % (len(rec['length']), a.out, ' (inputs + per-episode checksums)' if a.digest else ''))
     return 0
   rep = replay_on_device(load(a.fixture), a.device)
   print(json.dumps(rep))
