@@ -293,6 +293,46 @@ def test_fused_rollout_on_mutable_grids_smallest_shapes(env_id, n):
   env.close()
 
 
+@pytest.mark.parametrize('env_id,kw', [('MultiGrid-DoorKey-6x6-v0', dict(shaping=None, auto_reset=False)),
+                                       ('MultiGrid-DoorKey-8x8-v0', dict(shaping='v7')),
+                                       ('MultiGrid-Cluttered-v0', dict(competitive=True)),
+                                       ('MultiGrid-DoorKey-6x6-v0', dict(see_through_walls=True)),
+                                       ('MultiGrid-Meetup-Random-8x8-v0', dict(shaping=None)),
+                                       ('MultiGrid-FourRooms-15x15-v0', dict(shaping=None, competitive=True))])
+def test_fused_rollout_on_mutable_grids_other_configurations(env_id, kw):
+  """The switches the fused mutable-grid kernel keeps at run time — no shaping / the v7 shaper, no auto-reset, competitive done,
+  see-through walls — against the oracle configured the same way, and the float32 reward output against the float64 one."""
+  _need_gpu()
+  from multigrid_amd import registry
+  n, K = 600, 48
+  spec = registry.spec(env_id)
+  spec.update(kw)
+  spec['max_steps'] = 20
+  env = registry.make_batched(env_id, n, seed=31, max_steps=20, **kw)
+  f32 = registry.make_batched(env_id, n, seed=31, max_steps=20, reward_dtype='f32', **kw)
+  size = spec['size']
+  orc = c_oracle.OracleBatch(None, n, W=size, H=size, A=spec['n_agents'], V=spec['view_size'], max_steps=20,
+                             see_through=int(spec['see_through_walls']), competitive=int(spec['competitive']),
+                             shaping={'v8': 1, 'v7': 2, None: 0}[spec.get('shaping', 'v8')], auto_reset=int(spec.get('auto_reset', True)),
+                             seed=31, kind=spec['kind'], n_goals=spec.get('n_goals', 0), n_clutter=spec.get('n_clutter', 0),
+                             lava=spec.get('walls_are_lava', False), two_rooms=spec.get('two_rooms', False))
+  env.reset(); f32.reset(); orc.reset()
+  A, full = spec['n_agents'], env.obs_full is not None
+  traj = env.rollout_random(K)
+  t32 = f32.rollout_random(K)
+  img = traj['image'].cpu().numpy().reshape((K, n, -1) if full else (K, A, n, -1))
+  rew, done = traj['reward'].cpu().numpy(), traj['done'].cpu().numpy()
+  for k in range(K):
+    orc.step(None)
+    assert np.array_equal(img[k], orc.obs_image[0, :n] if full else orc.obs_image[:, :n]), (env_id, kw, k)
+    assert np.array_equal(rew[k].view(np.int64), orc.reward[:, :n].view(np.int64)) and np.array_equal(done[k], orc.done[:n]), (env_id, kw, k)
+  assert np.array_equal(env.agent_state.cpu().numpy().view(np.uint32), orc.agent_state()[:, :n])
+  assert t32['reward'].dtype == torch.float32 and torch.equal(t32['reward'], traj['reward'].float())
+  assert torch.equal(t32['image'], traj['image']) and torch.equal(f32.reward, env.reward.float())
+  assert env.check_errors() == 0 and f32.check_errors() == 0 and orc.errors() == 0
+  env.close(); f32.close()
+
+
 def test_fused_rollout_on_per_env_maps_and_the_step_by_step_form(monkeypatch):
   """Per-env layouts (mg_set_maps: table decode, per-env reset templates and shaper goals) through the fused kernel against the
   oracle holding the same layouts — drawn actions, then a caller's action ring — and the round-2 form of the same calls
