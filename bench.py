@@ -337,9 +337,11 @@ def main():
   if headline and args.also_envs and also_envs != args.envs:
     also = measure(also_envs, min(args.warmup, 100), min(args.steps, 500))
 
-  roll = None
+  roll = roll_small = None
   if headline and args.rollout_envs:
     roll = measure_rollout(args.rollout_envs, args.rollout_k, max(1, min(args.steps, 640) // args.rollout_k))
+    # BASELINE config 2's batch (4,096 envs per GPU): small enough for the rollout kernel that deals a chunk's agents out over waves
+    roll_small = measure_rollout(4096, 64, 10)
 
   # BASELINE config 4 (side measurement, never the headline): DoorKey-8x8 x 3 agents on per-env mutable grids — the step kernel
   # at the headline's batch size and its fused K-step rollout at config 3's per-GPU shard
@@ -397,6 +399,8 @@ def main():
                      'roofline_frac': a_ach / HBM_PEAK_GBS, 'launch': also['launch'], 'device_errors': also['errs']}
     if roll is not None:
       out['rollout'] = roll
+    if roll_small is not None:
+      out['rollout_config2'] = roll_small
     if cfg4 is not None:
       out['config4'] = cfg4
     if world == 1 and not args.no_cpu_baseline and headline:

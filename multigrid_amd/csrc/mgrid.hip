@@ -637,13 +637,18 @@ __device__ __forceinline__ pd_t<A> fixed_place(const Params& p, pd_t<A> pd, int 
 // p.obs_image / p.reward / p.dir_done (and p.env_state when store_state); ROLL = a step of the fused rollout
 // (mg_rollout_kernel): free-running like FAST, actions drawn on the device, and on its last step a second set of
 // destinations (the handle's own buffers, *2 below) besides the trajectory slot.
-template <int A, int V, bool TAB, bool FAST, bool ROLL = false>
+// SPLIT (mg_rollout_split_kernel, small batches): A waves share a chunk; every one of them runs the whole action phase — it is
+// serial in the drawn order and cheap — and then does ONE agent's share of the rest: agent `me`'s shaper, reward store, view and
+// image, its own word of env_state at the end; the wave of agent 0 also stores dir_done (and the actions, by way of
+// p.actions_out being null for the others) and the step word.  shw[] of the other agents is not maintained by this wave.
+template <int A, int V, bool TAB, bool FAST, bool ROLL = false, bool SPLIT = false>
 __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map, const double* dist, const uint32_t* table,
                                            const uint16_t* cidx, uint32_t* stage, int lane, int64_t env0,
                                            pd_t<A>& pd, uint32_t (&shw)[A], uint32_t& st, uint32_t actw, bool store_state,
                                            uint32_t& err_acc, uint8_t* obs2 = nullptr, double* reward2 = nullptr,
-                                           uint8_t* dd2 = nullptr) {
+                                           uint8_t* dd2 = nullptr, int me = 0) {
   static_assert(!ROLL || FAST, "the rollout is a free-running step");
+  static_assert(!SPLIT || ROLL, "agents are dealt out over waves in the fused rollout only");
   constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
   const int64_t n = env0 + lane;
   const bool active = n < p.n_envs;
@@ -723,6 +728,7 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
     for (int a = 0; a < A; ++a) {
       rew[a] = ((gbits >> a) & 1u) ? rgoal : 0.0;
       out_rew[a] = rew[a];
+      if (SPLIT && a != me) continue;                         // (wave-uniform)
       if (p.shaping != MG_SHAPING_NONE && MG_ABL != 4)
         shw[a] = v8_shape(p, dist, shw[a], pd_get(pd, a), (actw >> (3 * a)) & 7u, rew[a], out_rew[a]);
     }
@@ -731,6 +737,7 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
     if (active) {
 #pragma unroll
       for (int a = 0; a < A; ++a) {
+        if (SPLIT && a != me) continue;
         const int64_t i = (int64_t)a * p.stride + n;
         // (not in the FAST step instantiation: the wave-uniform branch alone cost the headline kernel 1.1 us of 50.8;
         //  a float32 handle steps through the general instantiation)
@@ -773,7 +780,14 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
   }
 
   if (active) {
-    if (store_state) {
+    if (SPLIT) {
+      if (store_state) {
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+          if (a == me) p.env_state[n * (A + 1) + a] = shw[a] | pd_get(pd, a);
+        if (me == 0) p.env_state[n * (A + 1) + A] = st;
+      }
+    } else if (store_state) {
       uint32_t wout[A];
 #pragma unroll
       for (int a = 0; a < A; ++a) wout[a] = shw[a] | pd_get(pd, a);
@@ -786,14 +800,16 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
       }
     }
     // obs['direction'][a] (multigrid.py:1083) for every agent + the collective done flag: one store
-    uint64_t dd = (uint64_t)done_flag << (8 * A);
+    if (!SPLIT || me == 0) {
+      uint64_t dd = (uint64_t)done_flag << (8 * A);
 #pragma unroll
-    for (int a = 0; a < A; ++a) dd |= (uint64_t)aw_d(pd_get(pd, a)) << (8 * a);
-    if (A + 1 <= 4) reinterpret_cast<uint32_t*>(p.dir_done)[n] = (uint32_t)dd;
-    else reinterpret_cast<uint64_t*>(p.dir_done)[n] = dd;
-    if (ROLL && dd2) {
-      if (A + 1 <= 4) reinterpret_cast<uint32_t*>(dd2)[n] = (uint32_t)dd;
-      else reinterpret_cast<uint64_t*>(dd2)[n] = dd;
+      for (int a = 0; a < A; ++a) dd |= (uint64_t)aw_d(pd_get(pd, a)) << (8 * a);
+      if (A + 1 <= 4) reinterpret_cast<uint32_t*>(p.dir_done)[n] = (uint32_t)dd;
+      else reinterpret_cast<uint64_t*>(p.dir_done)[n] = dd;
+      if (ROLL && dd2) {
+        if (A + 1 <= 4) reinterpret_cast<uint32_t*>(dd2)[n] = (uint32_t)dd;
+        else reinterpret_cast<uint64_t*>(dd2)[n] = dd;
+      }
     }
     err_acc |= err;
   }
@@ -802,6 +818,7 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
 #if MG_ABL != 2
 #pragma unroll
   for (int a = 0; a < (MG_ABL == 8 ? 1 : A); ++a) {   // (8: timing-only, one agent's view per wave — what splitting the agents over waves could buy)
+    if (SPLIT && a != me) continue;
     uint32_t s[NW + 1];
     uint64_t vm;
     if (TAB) table_view<V>(p, table, cidx, pd_get(pd, a), s, vm);
@@ -1046,6 +1063,80 @@ __global__ __launch_bounds__(kMaxBlock) void mg_rollout_kernel(const Params p) {
   if (err) atomicOr(p.err, err);
 }
 
+// The fused rollout for SMALL batches, agents dealt out over waves (the north-star mapping's idea, where it pays): a batch of a few
+// thousand envs leaves most of the chip idle and a step's time is the latency of one wave working through one chunk, 60 % of it
+// the three views and their staging.  Here A waves share a chunk (step_chunk<..., SPLIT>): each keeps the chunk's whole state in
+// its registers and runs the whole (serial, cheap) action phase, so they stay in step without ever talking to each other — same
+// Philox draws, same arithmetic — and each produces one agent's shaper, reward, view and image.  launch() picks it while A waves
+// per chunk still fit beside each other (mg_handle::roll_split_fn); beyond that the plain rollout kernel is the faster one, because
+// the action phase done A times over is then paid in throughput.  Lives in mgrid_dynroll.hip's code object.
+template <int A, int V, bool TAB, bool STD>
+__global__ __launch_bounds__(kMaxBlock) void mg_rollout_split_kernel(const Params p) {
+  constexpr int ROWB = ViewGeom<V>::ROWB, ENTW = ViewGeom<V>::ENTW;
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int nw = blockDim.x >> 6;
+  uint32_t* stage_all = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* table = reinterpret_cast<uint32_t*>(smem + (size_t)nw * kWave * ROWB);
+  double* dist = reinterpret_cast<double*>(table + (TAB ? p.n_entries * ENTW : 0));
+  uint32_t* map = reinterpret_cast<uint32_t*>(dist + p.W * p.H);
+  uint16_t* cidx = reinterpret_cast<uint16_t*>(map + p.PW * p.PH);
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
+  if (TAB) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.view_table);
+    uint4* dst = reinterpret_cast<uint4*>(table);
+    for (int i = tid; i < p.n_entries * ENTW / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = tid; i < p.W * p.H; i += blockDim.x) cidx[i] = p.cell_index[i];
+  }
+  for (int i = tid; i < p.PW * p.PH; i += blockDim.x) map[i] = p.map_pad[i];
+  for (int i = tid; i < p.W * p.H; i += blockDim.x) dist[i] = p.dist_lut[i];
+  __syncthreads();
+
+  uint32_t* stage = stage_all + wv * (kWave * ROWB / 4);
+  uint32_t err = 0;
+  const int64_t ustride = (int64_t)gridDim.x * nw, n_units = p.n_chunks * A;
+  const int64_t slot_obs = (int64_t)A * p.stride * ROWB, slot_rew = (int64_t)A * p.stride;
+  const int64_t slot_dd = p.stride * p.dd_bytes, slot_act = p.stride * kSlotWords<A>;
+  Params q = p;
+  if constexpr (STD) {
+    q.shaping = MG_SHAPING_V8; q.auto_reset = 1; q.competitive = 0; q.fixed_mode = MG_FIXED_OFF; q.reward_f32 = 0; q.see_through = 0;
+  }
+  for (int64_t u = (int64_t)blockIdx.x * nw + wv; u < n_units; u += ustride) {     // unit = (chunk, agent)
+    const int64_t c = u / A;
+    const int me = (int)(u - c * A);
+    ChunkIn in;
+    zero_chunk(in);
+    const int64_t n = c * kWave + lane;
+    if (A == 3) {
+      const uint4 w = reinterpret_cast<const uint4*>(p.env_state)[n];
+      in.q = u32x4{w.x, w.y, w.z, w.w};
+    } else {
+      const uint32_t* sp = p.env_state + n * (A + 1);
+      in.w0 = sp[0];
+      if (A >= 1) in.w1 = sp[1];
+      if (A >= 2) in.w2 = sp[2];
+      if (A >= 3) in.w3 = sp[3];
+      if (A >= 4) in.w4 = sp[4];
+      if (A >= 5) in.w5 = sp[5];
+    }
+    pd_t<A> pd;
+    uint32_t shw[A], st, actw;
+    unpack_chunk<A>(p, in, pd, shw, st, actw);
+#pragma unroll 1
+    for (int k = 0; k < p.n_roll; ++k) {
+      const bool last = k == p.n_roll - 1;
+      q.t = p.t + (uint64_t)k;
+      q.obs_image = p.traj_obs + k * slot_obs;
+      q.reward = reinterpret_cast<double*>(reinterpret_cast<char*>(p.traj_reward) + k * slot_rew * (!STD && p.reward_f32 ? 4 : 8));
+      q.dir_done = p.traj_dd + k * slot_dd;
+      q.actions_out = (p.traj_actions && me == 0) ? p.traj_actions + k * slot_act : nullptr;
+      q.actions = p.actions ? p.actions + k * slot_act : nullptr;
+      step_chunk<A, V, TAB, true, true, true>(q, map, dist, table, cidx, stage, lane, c * kWave, pd, shw, st, 0u, last, err,
+                                              last ? p.obs_image : nullptr, last ? p.reward : nullptr, last ? p.dir_done : nullptr, me);
+    }
+  }
+  if (err) atomicOr(p.err, err);
+}
+
 #include "mg_dyn.h"
 
 // The instantiations of the mutable-grid kernels, one to five agents for view 7, one to four for view 5 and the fully observed
@@ -1063,14 +1154,35 @@ __global__ __launch_bounds__(kMaxBlock) void mg_rollout_kernel(const Params p) {
 #endif
 
 #ifdef MG_TU_DYNROLL
-// ---- second translation unit (mgrid_dynroll.hip): nothing but the fused mutable-grid rollout kernels and their lookup ----
+// ---- second translation unit (mgrid_dynroll.hip): the mutable-grid kinds' fused rollout and free-running step kernels, the
+//      shared-map rollout with the agents dealt out over waves, and their lookup functions — nothing else ----
 struct DynRollEntry { int A, V; bool full; int pre; const void* fn[2]; const void* step_free[2]; };
 #define MG_DYN_ROLL(A, V, FULL, PRE) {A, FULL ? 0 : V, FULL, PRE, {(const void*)mg_dyn_rollout_kernel<A, V, FULL, PRE, false>, \
                                       FULL ? (const void*)nullptr : (const void*)mg_dyn_rollout_kernel<A, V, FULL, PRE, !FULL>}, \
                                       {(const void*)mg_dyn_kernel<A, V, FULL, PRE, false, true>, \
                                       FULL ? (const void*)nullptr : (const void*)mg_dyn_kernel<A, V, FULL, PRE, !FULL, true>}},
 const DynRollEntry kDynRoll[] = { MG_DYN_LIST(MG_DYN_ROLL) };
+
+// shared-map fused rollout with the agents dealt out over waves (mg_rollout_split_kernel): [table path][standard configuration]
+struct SplitEntry { int A, V; const void* fn[2][2]; };
+#define MG_SPLIT_TAB(A, V) {A, V, {{(const void*)mg_rollout_split_kernel<A, V, false, false>, (const void*)mg_rollout_split_kernel<A, V, false, true>}, \
+                                   {(const void*)mg_rollout_split_kernel<A, V, true, false>, (const void*)mg_rollout_split_kernel<A, V, true, true>}}},
+#define MG_SPLIT_GEN(A, V) {A, V, {{(const void*)mg_rollout_split_kernel<A, V, false, false>, (const void*)mg_rollout_split_kernel<A, V, false, true>}, \
+                                   {nullptr, nullptr}}},
+const SplitEntry kSplit[] = {
+#ifdef MG_MIN_BUILD
+    MG_SPLIT_TAB(3, 5)
+#else
+    MG_SPLIT_TAB(2, 5) MG_SPLIT_TAB(3, 5) MG_SPLIT_TAB(4, 5) MG_SPLIT_TAB(5, 5) MG_SPLIT_TAB(3, 3) MG_SPLIT_GEN(2, 7) MG_SPLIT_GEN(3, 7)
+#endif
+};
 }  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) const void* mg_rollsplit_kernel(int A, int V, int table, int std_cfg) {
+  for (const SplitEntry& e : kSplit)
+    if (e.A == A && e.V == V) return e.fn[table ? 1 : 0][std_cfg ? 1 : 0];
+  return nullptr;
+}
 
 // which: 0 = the fused rollout kernel, 1 = the free-running step kernel (mg_dyn_kernel<..., FREE>)
 extern "C" __attribute__((visibility("hidden"))) const void* mg_dynroll_kernel(int A, int V, int full, int pre, int dec, int which) {
@@ -1081,6 +1193,7 @@ extern "C" __attribute__((visibility("hidden"))) const void* mg_dynroll_kernel(i
 #else
 // (defined in mgrid_dynroll.hip's translation unit; C linkage, hidden: not part of the library's ABI)
 extern "C" __attribute__((visibility("hidden"))) const void* mg_dynroll_kernel(int A, int V, int full, int pre, int dec, int which);
+extern "C" __attribute__((visibility("hidden"))) const void* mg_rollsplit_kernel(int A, int V, int table, int std_cfg);
 
 // ---------------------------------------------------------------------------------------------
 // mg_step_noalloc: the per-GPU scratch its kernels use instead of a handle's hipMalloc'ed tables.
@@ -1353,6 +1466,7 @@ struct mg_handle {
   int dyn_waves_cu2[2];  // waves of the mutable-grid kernel (table-decoding / arithmetic) a CU can hold by registers
   int dyn_roll_waves_cu2[2];   // the same for the fused rollout kernels
   const void* dyn_roll_fn[2];  // those kernels (mgrid_dynroll.hip's code object), null where there is none
+  const void* roll_split_fn[2][2];   // mg_rollout_split_kernel [table path][standard configuration], null where there is none
   const void* dyn_free_fn[2];  // mg_dyn_kernel<..., FREE>: the free-running step (same code object)
   int dyn_free_waves_cu2[2];
   bool dyn_dec;          // this layout family's views decode their cell codes arithmetically (DEC, mg_dyn.h)
@@ -1602,6 +1716,24 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     }
     const bool std_cfg = p.shaping == MG_SHAPING_V8 && p.auto_reset && !p.competitive && h->fixed_mode == MG_FIXED_OFF &&
                          !p.reward_f32 && !c.see_through_walls && !debug_env("MG_DEBUG_ROLL_GENERAL");
+    // Small batches: the agents of a chunk dealt out over A waves (mg_rollout_split_kernel) while all those waves still sit
+    // side by side at two per SIMD — a step is then the latency of one wave, and a wave does a third of the views.  Beyond that
+    // the action phase done A times over costs throughput, and the plain kernel is the faster one.
+    const void* split_fn = h->roll_split_fn[rt ? 1 : 0][std_cfg ? 1 : 0];
+    bool split = split_fn && c.n_agents > 1 && h->n_chunks * c.n_agents <= (int64_t)h->n_cu * 8;
+    if (const char* e = debug_env("MG_DEBUG_ROLL_SPLIT")) split = split_fn && c.n_agents > 1 && atoi(e) != 0;   // tests / A-B timing
+    if (split) {
+      const int64_t units = h->n_chunks * c.n_agents;
+      const size_t fixed = lds_fixed_bytes(h, rt), per_wave = (size_t)kWave * c.view_size * c.view_size * 3;
+      int snw = rt ? 16 : 4;
+      while (snw > 1 && (fixed + snw * per_wave > (size_t)kLdsLimit || units < (int64_t)h->n_cu * snw)) snw >>= 1;
+      const size_t slds = fixed + snw * per_wave;
+      const int per_cu = std::max(1, std::min((int)((size_t)kLdsLimit / slds), 32 / snw));
+      const unsigned sgrid = (unsigned)std::min<int64_t>((units + snw - 1) / snw, (int64_t)h->n_cu * per_cu);
+      void* kargs[] = {&p};
+      HIP_TRY(hipLaunchKernel(split_fn, dim3(sgrid), dim3(snw * kWave), kargs, slds, h->stream));
+      return launch_ep_stats(h, op, mask, n_roll, roll);
+    }
     hipLaunchKernelGGL((std_cfg ? h->var->roll_std : h->var->roll)[rt ? 1 : 0], dim3(grid), dim3(nw * kWave), lds, h->stream, p);
     HIP_TRY(hipGetLastError());
     return launch_ep_stats(h, op, mask, n_roll, roll);
@@ -1731,6 +1863,8 @@ int mg_create(const mg_config* cfg, int device, mg_handle** out) {
   h->dyn_waves_cu2[0] = h->dyn_waves_cu2[1] = 8; h->dyn_dec = false; h->fixed_mode = 0; h->fixed_pd = 0; h->fixed_pd_hi = 0;
   h->dyn_roll_waves_cu2[0] = h->dyn_roll_waves_cu2[1] = 8;
   h->dyn_free_waves_cu2[0] = h->dyn_free_waves_cu2[1] = 8;
+  for (int t = 0; t < 2; ++t)
+    for (int sc = 0; sc < 2; ++sc) h->roll_split_fn[t][sc] = var ? mg_rollsplit_kernel(var->A, var->V, t, sc) : nullptr;
   for (int v = 0; v < 2; ++v) {
     h->dyn_roll_fn[v] = dvar ? mg_dynroll_kernel(dvar->A, dvar->V, dvar->full ? 1 : 0, dvar->pre, v, 0) : nullptr;
     h->dyn_free_fn[v] = dvar ? mg_dynroll_kernel(dvar->A, dvar->V, dvar->full ? 1 : 0, dvar->pre, v, 1) : nullptr;

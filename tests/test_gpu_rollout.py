@@ -95,6 +95,49 @@ def test_rollout_other_shapes(cluttered_cells, empty_cells):
     env.close()
 
 
+@pytest.mark.parametrize('A,V,kw', [(3, 5, {}), (2, 5, dict(shaping=None)), (4, 5, dict(shaping='v7')), (5, 5, dict(auto_reset=False)),
+                                    (3, 3, {}), (2, 7, {}), (3, 7, dict(reward_dtype='f32'))])
+@pytest.mark.parametrize('path', ['generic', 'table'])
+def test_agent_split_rollout_kernel_equals_the_plain_one(cluttered_cells, monkeypatch, path, A, V, kw):
+  """Small batches run mg_rollout_split_kernel (the agents of a chunk dealt out over A waves; MG_DEBUG_ROLL_SPLIT forces either
+  kernel): same trajectory, same handle state and buffers as the plain fused kernel, bit for bit, with drawn actions and with a
+  caller's ring, ragged batch, across auto-resets — and the drawn-action trajectory against the oracle."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  if path == 'table' and V == 7:
+    pytest.skip('view 7 has no table path')
+  monkeypatch.setenv('MG_DEBUG_ROLL_PATH', {'generic': '1', 'table': '2'}[path])
+  kp = 'table' if path == 'table' else 'auto'
+  n, K = 1500, 41
+  g = torch.Generator(device='cpu').manual_seed(A * 10 + V)
+  ring = torch.randint(0, 7, (K, n, A), dtype=torch.uint8, generator=g)
+  out = []
+  for split in ('1', '0'):
+    monkeypatch.setenv('MG_DEBUG_ROLL_SPLIT', split)
+    env = BatchedMultiGrid(cluttered_cells, n_envs=n, n_agents=A, view_size=V, max_steps=30, seed=A + V, kernel_path=kp, **kw)
+    env.reset()
+    t1 = env.rollout_random(K)
+    t2 = env.rollout(ring.to(env.device))
+    out.append(dict(img1=t1['image'].clone(), rew1=t1['reward'].clone(), act1=t1['actions'].clone(), done1=t1['done'].clone(), dir1=t1['direction'].clone(),
+                    img2=t2['image'].clone(), rew2=t2['reward'].clone(), done2=t2['done'].clone(),
+                    state=env._env_state[:n].clone(), obs=env._obs_image[:, :n].clone(), rew=env._reward[:, :n].clone(), dd=env._dir_done[:n].clone()))
+    assert env.check_errors() == 0 and env.step_index == 2 * K
+    env.close()
+  for k in out[0]:
+    a, b = out[0][k], out[1][k]
+    if a.dtype in (torch.float64, torch.float32):
+      a, b = a.view(torch.int64 if a.dtype == torch.float64 else torch.int32), b.view(torch.int64 if b.dtype == torch.float64 else torch.int32)
+    assert torch.equal(a, b), k
+  if kw.get('reward_dtype') != 'f32':
+    orc = c_oracle.OracleBatch(cluttered_cells, n, A=A, V=V, max_steps=30, shaping={'v8': 1, None: 0, 'v7': 2}[kw.get('shaping', 'v8')],
+                               auto_reset=int(kw.get('auto_reset', True)), seed=A + V)
+    orc.reset()
+    img, rew = out[0]['img1'].cpu().numpy().reshape(K, A, n, -1), out[0]['rew1'].cpu().numpy()
+    for k in range(K):
+      orc.step(None)
+      assert np.array_equal(img[k], orc.obs_image[:, :n]) and np.array_equal(rew[k].view(np.int64), orc.reward[:, :n].view(np.int64)), k
+
+
 def test_rollout_refusals(cluttered_cells, playground_cells):
   _need_gpu()
   from multigrid_amd import lib

@@ -14,9 +14,13 @@ def main():
   ap.add_argument('--k', type=int, default=32)
   ap.add_argument('--reps', type=int, default=20)
   ap.add_argument('--no-actions', action='store_true')
+  ap.add_argument('--lib', default=None, help='another build of libmgrid.so (tools/gpu.sh build ...) for A/B timing')
   args = ap.parse_args()
   import torch
   import multigrid_amd
+  if args.lib:
+    from multigrid_amd import lib
+    lib.LIB_PATH = os.path.abspath(args.lib)
   env = multigrid_amd.make_batched('MultiGrid-Cluttered-Fixed-15x15', args.envs, seed=1)
   env.reset()
   dev = env.device
@@ -39,7 +43,7 @@ def main():
   ms_single = e0.elapsed_time(e1) / (args.reps * args.k)
   n = args.envs
   b_roll = 225 + 4 + 24 + (0 if args.no_actions else 4) + 32.0 / args.k
-  print(json.dumps({'envs': n, 'K': args.k, 'roll_path': os.environ.get('MG_DEBUG_ROLL_PATH', 'auto'),
+  print(json.dumps({'envs': n, 'K': args.k, 'roll_path': os.environ.get('MG_DEBUG_ROLL_PATH', 'auto'), 'split': os.environ.get('MG_DEBUG_ROLL_SPLIT', 'auto'),
                     'us_per_step_fused': ms_roll * 1e3, 'us_per_step_single_step_random': ms_single * 1e3,
                     'agent_steps_per_s_fused': 3.0 * n / (ms_roll * 1e-3),
                     'frac_8TBs_fused_at_%.1fB' % b_roll: b_roll * n / (ms_roll * 1e-3) / 8e12,
