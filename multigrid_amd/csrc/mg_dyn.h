@@ -383,7 +383,8 @@ __device__ __forceinline__ uint32_t meetup_dist(const Params& p, pd_t<A> pd, con
 // fused rollout, whose grids stay in LDS from step to step: RESTORE puts back what the marks covered.
 template <int A, bool RESTORE = false>
 __device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uint8_t* gwave, const uint32_t* lut,
-                                          const uint16_t* cpc, pd_t<A> pd, int lane, uint8_t* gchunk, uint8_t* gchunk2 = nullptr) {
+                                          const uint16_t* cpc, pd_t<A> pd, int lane, uint8_t* gchunk, uint8_t* gchunk2 = nullptr,
+                                          int part = 0, int parts = 1) {     // this wave writes vectors part*64 + lane, + 64*parts, ... (split rollout)
   const int cells = p.W * p.H, FB = cells * 3;
   uint32_t under[A];
 #pragma unroll
@@ -402,14 +403,15 @@ __device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uin
   uint4* dst = reinterpret_cast<uint4*>(gchunk);
   uint4* dst2 = reinterpret_cast<uint4*>(gchunk2);   // wave-uniform; only the fused rollout's last step passes one
   const int nv = 4 * FB;                        // 16-byte vectors in the 64-image chunk
-  int e = 0, r0 = 16 * lane;                    // image index within the chunk and byte offset within it
+  const int vs = kWave * parts;                 // distance between two vectors of a lane
+  int e = 0, r0 = 16 * (lane + kWave * part);   // image index within the chunk and byte offset within it
   constexpr int UF = 2;                         // vectors per lane in flight (the dependent LDS reads of each overlap)
-  for (int q = lane; q < nv; q += UF * kWave) {
+  for (int q = lane + kWave * part; q < nv; q += UF * vs) {
     uint32_t k[UF][6], m[UF];
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
       while (r0 >= FB) { r0 -= FB; ++e; }
-      const bool live = q + u * kWave < nv;
+      const bool live = q + u * vs < nv;
       const int c0 = live ? (int)__umulhi((uint32_t)r0, 0x55555556u) : 0;   // r0 / 3
       m[u] = live ? (uint32_t)(r0 - 3 * c0) : 0u;
 #pragma unroll
@@ -418,7 +420,7 @@ __device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uin
         if (c >= cells) { c -= cells; ee += 1; }       // never past image 63: the chunk's last vector ends on its last byte
         k[u][j] = gwave[(int)cpc[c] * kCellB + ee];
       }
-      r0 += 16 * kWave;
+      r0 += 16 * vs;
     }
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
@@ -433,9 +435,9 @@ __device__ __forceinline__ void emit_full(const Params& p, uint8_t* g, const uin
       v.y = __builtin_amdgcn_alignbyte(s2, s1, m[u]);
       v.z = __builtin_amdgcn_alignbyte(s3, s2, m[u]);
       v.w = __builtin_amdgcn_alignbyte(s4, s3, m[u]);
-      if (q + u * kWave < nv) {
-        store_vec16(dst + q + u * kWave, v, p.nt_obs != 0);
-        if (dst2) store_vec16(dst2 + q + u * kWave, v, false);
+      if (q + u * vs < nv) {
+        store_vec16(dst + q + u * vs, v, p.nt_obs != 0);
+        if (dst2) store_vec16(dst2 + q + u * vs, v, false);
       }
     }
   }
@@ -479,6 +481,9 @@ template <int A> struct DynSt {
 };
 struct DynRoll {
   bool last;                 // the launch's last step: grids and state go back to HBM, and the outputs also go to the handle's own buffers
+  bool split; int me;        // small batches (p.roll_split): A waves share the chunk — each runs the whole action phase on its own LDS copy
+                             // of the grids and does agent `me`'s shaper, reward, view and image (fully observed: its share of the
+                             // image vectors); agent 0's wave also stores dir_done, carry, aux, the step word and the grids
   uint8_t* obs2; double* reward2; uint8_t* dd2;     // those buffers (null unless last)
 };
 
@@ -548,6 +553,8 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
                                           uint32_t& err_acc MG_PH_PARAM, DynSt<A>* S = nullptr, const DynRoll* R = nullptr) {
   constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
   const bool last = !ROLL || R->last;      // compile-time true outside the rollout
+  const bool split = ROLL && R->split;     // (wave-uniform) this wave does agent `me`'s share of the chunk only
+  const int me = ROLL ? R->me : 0;
   const int64_t n = env0 + lane;
   const bool active = n < p.n_envs;
   const uint32_t gid = (uint32_t)(p.gid_base + (uint64_t)n);
@@ -696,6 +703,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 #pragma unroll
     for (int a = 0; a < A; ++a) {
       out_rew[a] = rew[a];
+      if (split && a != me) continue;
       if (p.shaping != MG_SHAPING_NONE && MG_ABL != 4) {
         // get_goal_position (v8:159-169): the per-env scattered goal of a Cluttered layout, else the handle's
         const bool own = (p.kind == MG_KIND_CLUTTERED && p.n_goals != 0) || p.kind == MG_KIND_FOURROOMS || p.grid0 != nullptr;
@@ -707,6 +715,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     if (active) {
 #pragma unroll
       for (int a = 0; a < A; ++a) {
+        if (split && a != me) continue;
         const int64_t i = (int64_t)a * p.stride + n;
         if (p.reward_f32) reinterpret_cast<float*>(p.reward)[i] = (float)out_rew[a]; else p.reward[i] = out_rew[a];
         if (p.env_reward) p.env_reward[i] = rew[a];
@@ -829,7 +838,12 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 
   MG_PH(4);      // reset / auto-reset
   if (active) {
-    if (last) {
+    if (last && split) {               // each wave its own agent's word (only that one's shaper bits are kept up to date here)
+#pragma unroll
+      for (int a = 0; a < A; ++a)
+        if (a == me) p.env_state[n * (A + 1) + a] = shw[a] | pd_get(pd, a);
+      if (me == 0) p.env_state[n * (A + 1) + A] = st;
+    } else if (last) {
       if constexpr (A == 3) {          // the four words of an env are one aligned 16-byte vector
         reinterpret_cast<uint4*>(p.env_state)[n] = make_uint4(shw[0] | pd_get(pd, 0), shw[1] | pd_get(pd, 1), shw[2] | pd_get(pd, 2), st);
       } else {
@@ -837,18 +851,22 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
         for (int a = 0; a < A; ++a) p.env_state[n * (A + 1) + a] = shw[a] | pd_get(pd, a);
         p.env_state[n * (A + 1) + A] = st;
       }
+    }
+    if (last && (!split || me == 0)) {
       p.carry[n * kSlotWords<A>] = carry_to_kinds((uint32_t)carry);
       if constexpr (A > 4) p.carry[n * kSlotWords<A> + 1] = carry_to_kinds((uint32_t)(carry >> 32));
       if (p.aux) reinterpret_cast<uint4*>(p.aux)[n] = make_uint4(goal[0], goal[1], goal[2], past);
     }
-    uint64_t dd = (uint64_t)done_flag << (8 * A);
+    if (!split || me == 0) {
+      uint64_t dd = (uint64_t)done_flag << (8 * A);
 #pragma unroll
-    for (int a = 0; a < A; ++a) dd |= (uint64_t)aw_d(pd_get(pd, a)) << (8 * a);
-    if (A + 1 <= 4) reinterpret_cast<uint32_t*>(p.dir_done)[n] = (uint32_t)dd;
-    else reinterpret_cast<uint64_t*>(p.dir_done)[n] = dd;
-    if (ROLL && R->dd2) {
-      if (A + 1 <= 4) reinterpret_cast<uint32_t*>(R->dd2)[n] = (uint32_t)dd;
-      else reinterpret_cast<uint64_t*>(R->dd2)[n] = dd;
+      for (int a = 0; a < A; ++a) dd |= (uint64_t)aw_d(pd_get(pd, a)) << (8 * a);
+      if (A + 1 <= 4) reinterpret_cast<uint32_t*>(p.dir_done)[n] = (uint32_t)dd;
+      else reinterpret_cast<uint64_t*>(p.dir_done)[n] = dd;
+      if (ROLL && R->dd2) {
+        if (A + 1 <= 4) reinterpret_cast<uint32_t*>(R->dd2)[n] = (uint32_t)dd;
+        else reinterpret_cast<uint64_t*>(R->dd2)[n] = dd;
+      }
     }
     err_acc |= err;
   }
@@ -856,7 +874,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (last && __builtin_amdgcn_ballot_w64(dirty) != 0ull) {          // wave-uniform
+  if (last && (!split || me == 0) && __builtin_amdgcn_ballot_w64(dirty) != 0ull) {          // wave-uniform
     if (p.GW <= PRE) {
       // the mirror of the copy-in, unrolled the same way: the same (kept or recomputed) addresses, every LDS read of
       // the grid in flight before the first store
@@ -901,7 +919,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
 #if MG_ABL != 2
   if (FULL) {
     emit_full<A, ROLL>(p, g, reinterpret_cast<const uint8_t*>(gw), lut, cpc, pd, lane, p.obs_full + env0 * (int64_t)(p.W * p.H * 3),
-                 (ROLL && R->obs2) ? R->obs2 + env0 * (int64_t)(p.W * p.H * 3) : nullptr);
+                 (ROLL && R->obs2) ? R->obs2 + env0 * (int64_t)(p.W * p.H * 3) : nullptr, split ? me : 0, split ? A : 1);
   } else {
     // DEC: the one door whose state the cell code cannot show (DoorKey's, at (split_idx, door_idx) for the whole
     // episode) is read back once per step; gone (walked through while open: move_agent overwrites it) or open -> no overlay
@@ -914,6 +932,7 @@ __device__ __forceinline__ void dyn_chunk(const Params& p, const double* dist, c
     }
 #pragma unroll
     for (int a = 0; a < A; ++a) {
+      if (split && a != me) continue;
       uint32_t s[NW + 1];
       uint64_t vm;
 #if MG_ABL == 7   // timing-only: no view computation, the staging and the stores of (meaningless) images stay
@@ -1081,7 +1100,6 @@ __global__ __launch_bounds__(512, FULL ? MG_DYN_ROLL_FULL_WAVES : 1) void mg_dyn
   uint32_t* stage = L.stage_all + wv * (L.stage_b / 4);
   uint32_t* gw = L.grids + (size_t)wv * L.pcells * kCellW;
   uint32_t err = 0;
-  const int64_t cstride = (int64_t)gridDim.x * nw;
   const int64_t slot_obs = FULL ? p.stride * (int64_t)(cells * 3) : (int64_t)A * p.stride * ROWB;
   const int64_t slot_rew = (int64_t)A * p.stride * (p.reward_f32 ? 4 : 8);
   const int64_t slot_dd = p.stride * p.dd_bytes, slot_act = p.stride * kSlotWords<A>;
@@ -1089,13 +1107,28 @@ __global__ __launch_bounds__(512, FULL ? MG_DYN_ROLL_FULL_WAVES : 1) void mg_dyn
   // injection paths, the reset mask and the env_reward output fold away, and with them the scalar registers that carried
   // their pointers (DoorKey-8x8 16.4 -> 15.6 us per step at 131072 envs, Cluttered-15x15 17.2 -> 16.4)
   Params q = dyn_params<true>(p);
-  for (int64_t c = (int64_t)blockIdx.x * nw + wv; c < p.n_chunks; c += cstride) {
+  // small batches (p.roll_split): a chunk's agents dealt out over A waves, which each copy its grids into their own LDS and step
+  // them identically (same draws, same arithmetic), see DynRoll.  Those A waves sit in one workgroup (launch(): nw is a multiple
+  // of A then) and meet at a barrier between reading the chunk's state and the K steps, at whose end wave 0 writes it back: no
+  // wave can read what another has already advanced.  The trip count is the same for all waves of a workgroup; a wave without
+  // a chunk only keeps the barriers company.
+  DynRoll R;
+  R.split = p.roll_split != 0;
+  const int cpb = R.split ? nw / A : nw;
+  R.me = R.split ? wv % A : 0;
+  const int64_t n_groups = (p.n_chunks + cpb - 1) / cpb;
+  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int64_t c = g * cpb + (R.split ? wv / A : wv);
+    const bool valid = c < p.n_chunks;
     DynIn<A, PRE> cur = {};
-    dyn_load<A, PRE>(p, c * kWave, lane, cur);
-    dyn_wait<A, 0, PRE>(cur);            // once per K steps: nothing is in flight across code here
     DynSt<A> S;
-    dyn_begin<A, PRE>(p, gw, lane, c * kWave, cur, S);
-    DynRoll R;
+    if (valid) {
+      dyn_load<A, PRE>(p, c * kWave, lane, cur);
+      dyn_wait<A, 0, PRE>(cur);            // once per K steps: nothing is in flight across code here
+      dyn_begin<A, PRE>(p, gw, lane, c * kWave, cur, S);
+    }
+    if (R.split) __syncthreads();          // (uniform over the workgroup)
+    if (!valid) continue;
 #pragma unroll 1
     for (int k = 0; k < p.n_roll; ++k) {
       R.last = k == p.n_roll - 1;
@@ -1106,7 +1139,7 @@ __global__ __launch_bounds__(512, FULL ? MG_DYN_ROLL_FULL_WAVES : 1) void mg_dyn
       if (FULL) q.obs_full = p.traj_obs + k * slot_obs; else q.obs_image = p.traj_obs + k * slot_obs;
       q.reward = reinterpret_cast<double*>(reinterpret_cast<char*>(p.traj_reward) + k * slot_rew);
       q.dir_done = p.traj_dd + k * slot_dd;
-      q.actions_out = p.traj_actions ? p.traj_actions + k * slot_act : nullptr;
+      q.actions_out = (p.traj_actions && R.me == 0) ? p.traj_actions + k * slot_act : nullptr;
       q.actions = p.actions ? p.actions + k * slot_act : nullptr;
 #ifdef MG_PHASE_TIMERS
       uint32_t ph_acc[kPhases] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

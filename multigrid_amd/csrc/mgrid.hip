@@ -101,7 +101,7 @@ struct Params {
   int32_t gx, gy, LW, LH;      // shaper goal and the dims of the mutable-grid kernel's |dx|,|dy| distance LUT
   int32_t fixed_mode, fixed_pad;   // MG_FIXED_*: agents (re)start on fixed cells (shared-map kernels)
   uint64_t fixed_pd;           // their start cells, packed like pd (x | y<<6 per agent, 14 bits each)
-  uint32_t fixed_pd_hi, reserved_pd;   // the fifth agent's (five agents do not fit one u64)
+  uint32_t fixed_pd_hi, roll_split;    // the fifth agent's (five agents do not fit one u64); roll_split: mg_dyn_rollout_kernel deals a chunk's agents out over waves
   const uint16_t* scatter;     // int8x2 per (env, scattered object): injected layout draws
   uint32_t* aux;               // [stride][4]  MEETUP goal positions + past distances
   uint8_t* obs_full;           // [stride][W*H*3]  fully observed obs
@@ -1067,9 +1067,9 @@ __global__ __launch_bounds__(kMaxBlock) void mg_rollout_kernel(const Params p) {
 // thousand envs leaves most of the chip idle and a step's time is the latency of one wave working through one chunk, 60 % of it
 // the three views and their staging.  Here A waves share a chunk (step_chunk<..., SPLIT>): each keeps the chunk's whole state in
 // its registers and runs the whole (serial, cheap) action phase, so they stay in step without ever talking to each other — same
-// Philox draws, same arithmetic — and each produces one agent's shaper, reward, view and image.  launch() picks it while A waves
-// per chunk still fit beside each other (mg_handle::roll_split_fn); beyond that the plain rollout kernel is the faster one, because
-// the action phase done A times over is then paid in throughput.  Lives in mgrid_dynroll.hip's code object.
+// Philox draws, same arithmetic — and each produces one agent's shaper, reward, view and image.  launch() picks it while a CU's
+// share of chunks times A fits one workgroup (mg_handle::roll_split_fn); beyond that the plain rollout kernel is the faster one,
+// because the action phase done A times over is then paid in throughput.  Lives in mgrid_dynroll.hip's code object.
 template <int A, int V, bool TAB, bool STD>
 __global__ __launch_bounds__(kMaxBlock) void mg_rollout_split_kernel(const Params p) {
   constexpr int ROWB = ViewGeom<V>::ROWB, ENTW = ViewGeom<V>::ENTW;
@@ -1093,31 +1093,39 @@ __global__ __launch_bounds__(kMaxBlock) void mg_rollout_split_kernel(const Param
 
   uint32_t* stage = stage_all + wv * (kWave * ROWB / 4);
   uint32_t err = 0;
-  const int64_t ustride = (int64_t)gridDim.x * nw, n_units = p.n_chunks * A;
   const int64_t slot_obs = (int64_t)A * p.stride * ROWB, slot_rew = (int64_t)A * p.stride;
   const int64_t slot_dd = p.stride * p.dd_bytes, slot_act = p.stride * kSlotWords<A>;
   Params q = p;
   if constexpr (STD) {
     q.shaping = MG_SHAPING_V8; q.auto_reset = 1; q.competitive = 0; q.fixed_mode = MG_FIXED_OFF; q.reward_f32 = 0; q.see_through = 0;
   }
-  for (int64_t u = (int64_t)blockIdx.x * nw + wv; u < n_units; u += ustride) {     // unit = (chunk, agent)
-    const int64_t c = u / A;
-    const int me = (int)(u - c * A);
+  // the A waves of a chunk sit in one workgroup (launch(): nw is a multiple of A) and meet at a barrier between reading the chunk's
+  // state and the K steps, at whose end they write it back: no wave can read what another has already advanced.  The trip count
+  // is the same for all waves of the workgroup; a wave without a chunk only keeps the barriers company.
+  const int cpb = nw / A, me = wv % A;
+  const int64_t n_groups = (p.n_chunks + cpb - 1) / cpb;
+  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int64_t c = g * cpb + wv / A;
+    const bool valid = c < p.n_chunks;
     ChunkIn in;
     zero_chunk(in);
     const int64_t n = c * kWave + lane;
-    if (A == 3) {
-      const uint4 w = reinterpret_cast<const uint4*>(p.env_state)[n];
-      in.q = u32x4{w.x, w.y, w.z, w.w};
-    } else {
-      const uint32_t* sp = p.env_state + n * (A + 1);
-      in.w0 = sp[0];
-      if (A >= 1) in.w1 = sp[1];
-      if (A >= 2) in.w2 = sp[2];
-      if (A >= 3) in.w3 = sp[3];
-      if (A >= 4) in.w4 = sp[4];
-      if (A >= 5) in.w5 = sp[5];
+    if (valid) {
+      if (A == 3) {
+        const uint4 w = reinterpret_cast<const uint4*>(p.env_state)[n];
+        in.q = u32x4{w.x, w.y, w.z, w.w};
+      } else {
+        const uint32_t* sp = p.env_state + n * (A + 1);
+        in.w0 = sp[0];
+        if (A >= 1) in.w1 = sp[1];
+        if (A >= 2) in.w2 = sp[2];
+        if (A >= 3) in.w3 = sp[3];
+        if (A >= 4) in.w4 = sp[4];
+        if (A >= 5) in.w5 = sp[5];
+      }
     }
+    __syncthreads();
+    if (!valid) continue;
     pd_t<A> pd;
     uint32_t shw[A], st, actw;
     unpack_chunk<A>(p, in, pd, shw, st, actw);
@@ -1526,7 +1534,9 @@ const char* debug_env(const char* name) {
 bool launch_uses_table(const mg_handle* h) {
   if (!h->use_table) return false;
   if (h->cfg.kernel_path == MG_PATH_TABLE) return true;
-  return h->n_chunks <= (int64_t)h->n_cu * 16 * kUpfront;
+  // a step launch pays ~3 us of LDS fill per workgroup for the table, which only pays off from ~64K envs
+  // (measured: 32768 envs 10.4 us generic vs 11.0 us table; 131072 envs 14.7 vs 12.5)
+  return h->n_chunks >= 1024 && h->n_chunks <= (int64_t)h->n_cu * 16 * kUpfront;
 }
 
 // Whether the obs images leave with non-temporal stores (store_vec16): when a launch writes more obs than the 256 MB
@@ -1576,7 +1586,10 @@ int dyn_dec_index(const mg_handle* h) {
 
 // Mutable-grid launch geometry: 4 waves per workgroup (fewer for small batches), as many workgroups
 // per CU as LDS allows; persistent over chunks.
-void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* lds_out, int which = 0) {   // which: 0 general step, 1 rollout, 2 free step
+// parts > 1 (the rollout with a chunk's agents dealt out over waves): a chunk takes `parts` waves of ONE workgroup — they meet at a
+// barrier between reading the chunk's state and writing it back — so the workgroup is a multiple of that; false if none fits LDS.
+// *one_trip: every chunk has its waves resident at once (no workgroup takes a second turn) — what that mapping needs to pay.
+bool dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* lds_out, int which = 0, int parts = 1, bool* one_trip = nullptr) {   // which: 0 general step, 1 rollout, 2 free step
   const mg_config& c = h->cfg;
   const size_t rowb = h->full_obs ? 0 : (size_t)c.view_size * c.view_size * 3;   // fully observed images are not staged
   const size_t fixed = ((size_t)h->LW * h->LH * 8 + (size_t)c.width * c.height * 4 + 256 * 4 + (size_t)h->GW * 4 + 8 + 15) / 16 * 16;
@@ -1586,23 +1599,29 @@ void dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* l
   // whatever fits 160 KB of LDS.  Ties go to the smaller workgroup; small batches shrink it further so that
   // every CU gets work.
   const int kDynWavesPerCU = (which == 1 ? h->dyn_roll_waves_cu2 : which == 2 ? h->dyn_free_waves_cu2 : h->dyn_waves_cu2)[dyn_dec_index(h)];
-  int nw = 1, best = 0;
-  for (int cand = 1; cand <= 8; ++cand) {
+  int nw = 0, best = 0;
+  for (int cand = parts; cand <= std::max(8, parts); cand += parts) {
     const size_t need = fixed + cand * per_wave;
     if (need > (size_t)kLdsLimit) break;
-    const int resident = std::min(kDynWavesPerCU, cand * (int)((size_t)kLdsLimit / need));
+    const int resident = parts == 1 ? std::min(kDynWavesPerCU, cand * (int)((size_t)kLdsLimit / need))
+                                    : cand * std::min(kDynWavesPerCU / cand, (int)((size_t)kLdsLimit / need));   // whole workgroups
     if (resident > best) { best = resident; nw = cand; }
   }
-  while (nw > 1 && h->n_chunks < (int64_t)h->n_cu * nw) nw >>= 1;
+  if (nw == 0) return false;
+  if (parts == 1) { while (nw > 1 && h->n_chunks < (int64_t)h->n_cu * nw) nw >>= 1; }
+  else { while (nw > parts && h->n_chunks * parts < (int64_t)h->n_cu * nw) nw -= parts; }
   const size_t lds = fixed + nw * per_wave;
   int per_cu = (int)((size_t)kLdsLimit / lds);
   per_cu = std::max(1, std::min(per_cu, kDynWavesPerCU / nw));
-  const int64_t blocks = (h->n_chunks + nw - 1) / nw;
+  const int cpb = nw / parts;                       // chunks per workgroup
+  const int64_t blocks = (h->n_chunks + cpb - 1) / cpb;
   *nw_out = nw;
   *grid_out = (unsigned)std::min<int64_t>(blocks, (int64_t)h->n_cu * per_cu);
+  if (one_trip) *one_trip = blocks <= (int64_t)h->n_cu * per_cu;
   if (const char* e = debug_env("MG_DEBUG_GRID"))   // tuning experiments / tests only
     *grid_out = (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, atoi(e)));
   *lds_out = lds;
+  return true;
 }
 
 // After a reset / step / rollout launch: fold its rewards and done flags into the episode statistics (same stream).
@@ -1659,7 +1678,7 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
   p.carry = h->carry; p.grid = h->grid;
   p.n_goals = c.gen_n_goals; p.n_clutter = c.gen_n_clutter; p.gen_flags = c.gen_flags; p.full_obs = h->full_obs ? 1 : 0;
   p.gx = h->gx; p.gy = h->gy; p.LW = h->LW; p.LH = h->LH;
-  p.fixed_mode = h->fixed_mode; p.fixed_pd = h->fixed_pd; p.fixed_pd_hi = h->fixed_pd_hi; p.reserved_pd = 0;
+  p.fixed_mode = h->fixed_mode; p.fixed_pd = h->fixed_pd; p.fixed_pd_hi = h->fixed_pd_hi; p.roll_split = 0;
   p.scatter = reinterpret_cast<const uint16_t*>(scatter); p.aux = h->aux; p.obs_full = h->obs_full;
   p.nt_obs = launch_streams_obs(h);
   p.reward_f32 = c.reward_dtype == MG_REWARD_F32 ? 1 : 0;
@@ -1678,7 +1697,16 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
       p.traj_actions = actions ? nullptr : reinterpret_cast<uint32_t*>(roll->actions);
       p.nt_obs = 0xFF;
       if (const char* e = debug_env("MG_DEBUG_NT")) p.nt_obs = atoi(e);   // tuning experiments only
-      dyn_geometry(h, &nw, &grid, &lds, 1);
+      // small batches: a chunk's agents dealt out over waves, as in the shared-map rollout (mg_rollout_split_kernel); the same
+      // kernel does both, told by p.roll_split.  Taken while every chunk's A waves are resident at once (A = 3: up to 32768
+      // envs at two waves per SIMD, 65536 for the fully observed kinds' three); beyond that the plain mapping is the faster one.
+      bool split = false, one_trip = false;
+      if (c.n_agents > 1 && dyn_geometry(h, &nw, &grid, &lds, 1, c.n_agents, &one_trip)) {
+        const char* e = debug_env("MG_DEBUG_ROLL_SPLIT");   // tests / A-B timing
+        split = e ? atoi(e) != 0 : one_trip;
+      }
+      if (!split) dyn_geometry(h, &nw, &grid, &lds, 1);
+      p.roll_split = split ? 1u : 0u;
       void* kargs[] = {&p};
       HIP_TRY(hipLaunchKernel(h->dyn_roll_fn[dyn_dec_index(h)], dim3(grid), dim3(nw * kWave), kargs, lds, h->stream));
       return launch_ep_stats(h, op, mask, n_roll, roll);
@@ -1702,7 +1730,8 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     // Fused rollout: the trajectory is written once and far exceeds the caches, so every image is streamed.  Which path:
     // the table kernel (persistent, 16 waves per workgroup, its 44 KB table fill now paid once per K steps) whenever the
     // handle has a table, unless MG_DEBUG_ROLL_PATH forces one (tuning experiments only).
-    bool rt = h->use_table && h->var->roll[1] != nullptr;
+    // (small batches, AUTO: from four steps per launch on — below that the fill costs more than the table saves)
+    bool rt = h->use_table && h->var->roll[1] != nullptr && (c.kernel_path == MG_PATH_TABLE || h->n_chunks >= 1024 || n_roll >= 4);
     if (const char* e = debug_env("MG_DEBUG_ROLL_PATH")) rt = rt && atoi(e) == MG_PATH_TABLE;
     p.n_roll = n_roll;
     p.traj_obs = roll->obs_image; p.traj_reward = roll->reward; p.traj_dd = roll->dir_done;
@@ -1710,26 +1739,41 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     p.nt_obs = 0xFF; p.random_actions = 1;
     if (const char* e = debug_env("MG_DEBUG_NT")) p.nt_obs = atoi(e);   // tuning experiments only
     launch_geometry(h, rt, &nw, &grid, &lds);
+    const size_t fixed = lds_fixed_bytes(h, rt), per_wave = (size_t)kWave * c.view_size * c.view_size * 3;
+    const int64_t per_cu_chunks = (h->n_chunks + h->n_cu - 1) / h->n_cu;
     if (!rt) {                                   // persistent on the generic path too: up to four chunks per wave, stepped together
       const int per_cu = std::max(1, std::min((int)((size_t)kLdsLimit / lds), 32 / nw));
       grid = (unsigned)std::min<int64_t>(grid, (int64_t)h->n_cu * per_cu);
+    } else if (per_cu_chunks < 16 && !debug_env("MG_DEBUG_NW") && !debug_env("MG_DEBUG_GRID")) {
+      // fewer chunks than 16 per CU: one workgroup per CU with just as many waves as the CU's share (any number, not a power of
+      // two), so that no wave takes a second chunk while wave slots stand empty
+      int w = (int)per_cu_chunks;
+      while (w > 1 && fixed + w * per_wave > (size_t)kLdsLimit) --w;
+      nw = w; lds = fixed + nw * per_wave;
+      const int per_cu = std::max(1, std::min((int)((size_t)kLdsLimit / lds), 32 / nw));
+      grid = (unsigned)std::min<int64_t>((h->n_chunks + nw - 1) / nw, (int64_t)h->n_cu * per_cu);
     }
     const bool std_cfg = p.shaping == MG_SHAPING_V8 && p.auto_reset && !p.competitive && h->fixed_mode == MG_FIXED_OFF &&
                          !p.reward_f32 && !c.see_through_walls && !debug_env("MG_DEBUG_ROLL_GENERAL");
-    // Small batches: the agents of a chunk dealt out over A waves (mg_rollout_split_kernel) while all those waves still sit
-    // side by side at two per SIMD — a step is then the latency of one wave, and a wave does a third of the views.  Beyond that
-    // the action phase done A times over costs throughput, and the plain kernel is the faster one.
+    // Small batches: the agents of a chunk dealt out over A waves (mg_rollout_split_kernel) — a step is then the latency of one
+    // wave, and a wave does a third of the views.  A chunk's A waves sit in one workgroup (they meet at a barrier between reading
+    // its state and writing it back).  Table path: one workgroup per CU holding the CU's share of chunks, while that share
+    // times A fits the workgroup's 16 waves (three agents: up to 81920 envs).  Generic path (four waves' staging per
+    // workgroup): a chunk per workgroup, while all of them are resident at two waves per SIMD.  Beyond that the action phase
+    // done A times over costs throughput, and the plain kernel is the faster one.
     const void* split_fn = h->roll_split_fn[rt ? 1 : 0][std_cfg ? 1 : 0];
-    bool split = split_fn && c.n_agents > 1 && h->n_chunks * c.n_agents <= (int64_t)h->n_cu * 8;
-    if (const char* e = debug_env("MG_DEBUG_ROLL_SPLIT")) split = split_fn && c.n_agents > 1 && atoi(e) != 0;   // tests / A-B timing
+    const int A = c.n_agents, cap = std::max(1, (rt ? 16 : 4) / A);
+    int cpb = rt ? (int)std::min<int64_t>(per_cu_chunks, cap) : 1;       // chunks per workgroup
+    while (cpb > 1 && fixed + (size_t)cpb * A * per_wave > (size_t)kLdsLimit) --cpb;
+    bool split = split_fn && A > 1 && (rt ? per_cu_chunks <= cpb : h->n_chunks * A <= (int64_t)h->n_cu * 8);
+    if (const char* e = debug_env("MG_DEBUG_ROLL_SPLIT")) split = split_fn && A > 1 && atoi(e) != 0;   // tests / A-B timing
     if (split) {
-      const int64_t units = h->n_chunks * c.n_agents;
-      const size_t fixed = lds_fixed_bytes(h, rt), per_wave = (size_t)kWave * c.view_size * c.view_size * 3;
-      int snw = rt ? 16 : 4;
-      while (snw > 1 && (fixed + snw * per_wave > (size_t)kLdsLimit || units < (int64_t)h->n_cu * snw)) snw >>= 1;
+      if (const char* e = debug_env("MG_DEBUG_SPLIT_CPB")) cpb = std::max(1, std::min(atoi(e), cap));   // tuning experiments only
+      const int snw = cpb * A;
       const size_t slds = fixed + snw * per_wave;
       const int per_cu = std::max(1, std::min((int)((size_t)kLdsLimit / slds), 32 / snw));
-      const unsigned sgrid = (unsigned)std::min<int64_t>((units + snw - 1) / snw, (int64_t)h->n_cu * per_cu);
+      unsigned sgrid = (unsigned)std::min<int64_t>((h->n_chunks + cpb - 1) / cpb, (int64_t)h->n_cu * per_cu);
+      if (const char* e = debug_env("MG_DEBUG_GRID")) sgrid = (unsigned)std::max(1, std::min<int>(sgrid, atoi(e)));   // tests only
       void* kargs[] = {&p};
       HIP_TRY(hipLaunchKernel(split_fn, dim3(sgrid), dim3(snw * kWave), kargs, slds, h->stream));
       return launch_ep_stats(h, op, mask, n_roll, roll);
@@ -2039,10 +2083,9 @@ int mg_set_static_map(mg_handle* h, const uint8_t* cells) {
   // part is a pure function of (cell, dir)).
   const Variant* var = h->var;
   std::vector<uint32_t> table;
-  // AUTO: the table costs ~3 us of LDS fill per workgroup, which only pays off from ~64K envs
-  // (measured: 32768 envs 10.4 us generic vs 11.0 us table; 131072 envs 14.7 vs 12.5)
-  bool use_table = var->table[0] != nullptr && cfg.kernel_path != MG_PATH_GENERIC &&
-                   (cfg.kernel_path == MG_PATH_TABLE || h->n_chunks >= 1024);
+  // AUTO: the handle has a table whatever its size — a fused rollout pays the fill once per K steps and takes the table path
+  // at any batch size; which kernel a step launch runs is launch_uses_table()'s decision
+  bool use_table = var->table[0] != nullptr && cfg.kernel_path != MG_PATH_GENERIC;
   if (use_table) {
     h->n_entries = n_free * 4;
     table.assign((size_t)h->n_entries * var->entw, 0u);

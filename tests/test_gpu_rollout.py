@@ -114,6 +114,10 @@ def test_agent_split_rollout_kernel_equals_the_plain_one(cluttered_cells, monkey
   out = []
   for split in ('1', '0'):
     monkeypatch.setenv('MG_DEBUG_ROLL_SPLIT', split)
+    if split == '1':
+      monkeypatch.setenv('MG_DEBUG_GRID', '5')   # workgroups take several turns: a chunk's waves read its state before any writes it back
+    else:
+      monkeypatch.delenv('MG_DEBUG_GRID', raising=False)
     env = BatchedMultiGrid(cluttered_cells, n_envs=n, n_agents=A, view_size=V, max_steps=30, seed=A + V, kernel_path=kp, **kw)
     env.reset()
     t1 = env.rollout_random(K)
@@ -265,14 +269,19 @@ _FUSED_DYN = [('MultiGrid-DoorKey-6x6-v0', 1000, 37, 2, None), ('MultiGrid-DoorK
               ('MultiGrid-WallsAreLava-v0', 450, 40, 1, None)]
 
 
+@pytest.mark.parametrize('split', ['0', '1'])
 @pytest.mark.parametrize('env_id,n,K,calls,grid', _FUSED_DYN)
-def test_fused_rollout_on_mutable_grids_matches_the_oracle(monkeypatch, env_id, n, K, calls, grid):
+def test_fused_rollout_on_mutable_grids_matches_the_oracle(monkeypatch, env_id, n, K, calls, grid, split):
   """mg_dyn_rollout_kernel: K fused free-running steps on per-env grids (layouts, pickups, doors, respawns, auto-resets inside
-  the launch) against the oracle stepping K times, every trajectory slot and the handle's state afterwards, bit for bit."""
+  the launch) against the oracle stepping K times, every trajectory slot and the handle's state afterwards, bit for bit — a
+  wave per chunk, and (split, what batches this small get by default) a chunk's agents dealt out over the waves of a workgroup."""
   _need_gpu()
   from multigrid_amd import registry
   if env_id not in registry.registered_ids():
     pytest.skip('id not registered')
+  if split == '1' and registry.spec(env_id)['n_agents'] == 1:
+    pytest.skip('one agent: nothing to deal out')
+  monkeypatch.setenv('MG_DEBUG_ROLL_SPLIT', split)
   if grid:
     monkeypatch.setenv('MG_DEBUG_GRID', grid)
   spec = registry.spec(env_id)
