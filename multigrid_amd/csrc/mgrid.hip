@@ -637,16 +637,17 @@ __device__ __forceinline__ pd_t<A> fixed_place(const Params& p, pd_t<A> pd, int 
 // p.obs_image / p.reward / p.dir_done (and p.env_state when store_state); ROLL = a step of the fused rollout
 // (mg_rollout_kernel): free-running like FAST, actions drawn on the device, and on its last step a second set of
 // destinations (the handle's own buffers, *2 below) besides the trajectory slot.
-// SPLIT (mg_rollout_split_kernel, small batches): A waves share a chunk; every one of them runs the whole action phase — it is
-// serial in the drawn order and cheap — and then does ONE agent's share of the rest: agent `me`'s shaper, reward store, view and
-// image, its own word of env_state at the end; the wave of agent 0 also stores dir_done (and the actions, by way of
-// p.actions_out being null for the others) and the step word.  shw[] of the other agents is not maintained by this wave.
+// SPLIT (mg_rollout_split_kernel, small batches): two to A waves share a chunk; every one of them runs the whole action phase —
+// it is serial in the drawn order and cheap — and then does its own agents' share of the rest (`mine`, a wave-uniform bit per
+// agent): their shaper, reward store, view and image, their words of env_state at the end; the wave of agent 0 also stores
+// dir_done (and the actions, by way of p.actions_out being null for the others) and the step word.  shw[] of the other agents
+// is not maintained by this wave.
 template <int A, int V, bool TAB, bool FAST, bool ROLL = false, bool SPLIT = false>
 __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map, const double* dist, const uint32_t* table,
                                            const uint16_t* cidx, uint32_t* stage, int lane, int64_t env0,
                                            pd_t<A>& pd, uint32_t (&shw)[A], uint32_t& st, uint32_t actw, bool store_state,
                                            uint32_t& err_acc, uint8_t* obs2 = nullptr, double* reward2 = nullptr,
-                                           uint8_t* dd2 = nullptr, int me = 0) {
+                                           uint8_t* dd2 = nullptr, uint32_t mine = ~0u) {
   static_assert(!ROLL || FAST, "the rollout is a free-running step");
   static_assert(!SPLIT || ROLL, "agents are dealt out over waves in the fused rollout only");
   constexpr int ROWB = ViewGeom<V>::ROWB, NW = ViewGeom<V>::NW;
@@ -728,7 +729,7 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
     for (int a = 0; a < A; ++a) {
       rew[a] = ((gbits >> a) & 1u) ? rgoal : 0.0;
       out_rew[a] = rew[a];
-      if (SPLIT && a != me) continue;                         // (wave-uniform)
+      if (SPLIT && !((mine >> a) & 1u)) continue;             // (wave-uniform)
       if (p.shaping != MG_SHAPING_NONE && MG_ABL != 4)
         shw[a] = v8_shape(p, dist, shw[a], pd_get(pd, a), (actw >> (3 * a)) & 7u, rew[a], out_rew[a]);
     }
@@ -737,7 +738,7 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
     if (active) {
 #pragma unroll
       for (int a = 0; a < A; ++a) {
-        if (SPLIT && a != me) continue;
+        if (SPLIT && !((mine >> a) & 1u)) continue;
         const int64_t i = (int64_t)a * p.stride + n;
         // (not in the FAST step instantiation: the wave-uniform branch alone cost the headline kernel 1.1 us of 50.8;
         //  a float32 handle steps through the general instantiation)
@@ -784,8 +785,8 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
       if (store_state) {
 #pragma unroll
         for (int a = 0; a < A; ++a)
-          if (a == me) p.env_state[n * (A + 1) + a] = shw[a] | pd_get(pd, a);
-        if (me == 0) p.env_state[n * (A + 1) + A] = st;
+          if ((mine >> a) & 1u) p.env_state[n * (A + 1) + a] = shw[a] | pd_get(pd, a);
+        if (mine & 1u) p.env_state[n * (A + 1) + A] = st;
       }
     } else if (store_state) {
       uint32_t wout[A];
@@ -800,7 +801,7 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
       }
     }
     // obs['direction'][a] (multigrid.py:1083) for every agent + the collective done flag: one store
-    if (!SPLIT || me == 0) {
+    if (!SPLIT || (mine & 1u)) {
       uint64_t dd = (uint64_t)done_flag << (8 * A);
 #pragma unroll
       for (int a = 0; a < A; ++a) dd |= (uint64_t)aw_d(pd_get(pd, a)) << (8 * a);
@@ -818,7 +819,7 @@ __device__ __forceinline__ void step_chunk(const Params& p, const uint32_t* map,
 #if MG_ABL != 2
 #pragma unroll
   for (int a = 0; a < (MG_ABL == 8 ? 1 : A); ++a) {   // (8: timing-only, one agent's view per wave — what splitting the agents over waves could buy)
-    if (SPLIT && a != me) continue;
+    if (SPLIT && !((mine >> a) & 1u)) continue;
     uint32_t s[NW + 1];
     uint64_t vm;
     if (TAB) table_view<V>(p, table, cidx, pd_get(pd, a), s, vm);
@@ -1099,13 +1100,16 @@ __global__ __launch_bounds__(kMaxBlock) void mg_rollout_split_kernel(const Param
   if constexpr (STD) {
     q.shaping = MG_SHAPING_V8; q.auto_reset = 1; q.competitive = 0; q.fixed_mode = MG_FIXED_OFF; q.reward_f32 = 0; q.see_through = 0;
   }
-  // the A waves of a chunk sit in one workgroup (launch(): nw is a multiple of A) and meet at a barrier between reading the chunk's
-  // state and the K steps, at whose end they write it back: no wave can read what another has already advanced.  The trip count
-  // is the same for all waves of the workgroup; a wave without a chunk only keeps the barriers company.
-  const int cpb = nw / A, me = wv % A;
+  // the waves of a chunk — p.roll_split of them, two to A; wave `me` takes agents me, me + parts, ... — sit in one workgroup
+  // (launch(): nw is a multiple of parts) and meet at a barrier between reading the chunk's state and the K steps, at whose end
+  // they write it back: no wave can read what another has already advanced.  The trip count is the same for all waves of the
+  // workgroup; a wave without a chunk only keeps the barriers company.
+  const int parts = (int)p.roll_split, cpb = nw / parts, me = wv % parts;
+  uint32_t mine = 0u;
+  for (int a = me; a < A; a += parts) mine |= 1u << a;
   const int64_t n_groups = (p.n_chunks + cpb - 1) / cpb;
   for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    const int64_t c = g * cpb + wv / A;
+    const int64_t c = g * cpb + wv / parts;
     const bool valid = c < p.n_chunks;
     ChunkIn in;
     zero_chunk(in);
@@ -1139,7 +1143,7 @@ __global__ __launch_bounds__(kMaxBlock) void mg_rollout_split_kernel(const Param
       q.actions_out = (p.traj_actions && me == 0) ? p.traj_actions + k * slot_act : nullptr;
       q.actions = p.actions ? p.actions + k * slot_act : nullptr;
       step_chunk<A, V, TAB, true, true, true>(q, map, dist, table, cidx, stage, lane, c * kWave, pd, shw, st, 0u, last, err,
-                                              last ? p.obs_image : nullptr, last ? p.reward : nullptr, last ? p.dir_done : nullptr, me);
+                                              last ? p.obs_image : nullptr, last ? p.reward : nullptr, last ? p.dir_done : nullptr, mine);
     }
   }
   if (err) atomicOr(p.err, err);
@@ -1755,21 +1759,35 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     }
     const bool std_cfg = p.shaping == MG_SHAPING_V8 && p.auto_reset && !p.competitive && h->fixed_mode == MG_FIXED_OFF &&
                          !p.reward_f32 && !c.see_through_walls && !debug_env("MG_DEBUG_ROLL_GENERAL");
-    // Small batches: the agents of a chunk dealt out over A waves (mg_rollout_split_kernel) — a step is then the latency of one
-    // wave, and a wave does a third of the views.  A chunk's A waves sit in one workgroup (they meet at a barrier between reading
-    // its state and writing it back).  Table path: one workgroup per CU holding the CU's share of chunks, while that share
-    // times A fits the workgroup's 16 waves (three agents: up to 81920 envs).  Generic path (four waves' staging per
-    // workgroup): a chunk per workgroup, while all of them are resident at two waves per SIMD.  Beyond that the action phase
-    // done A times over costs throughput, and the plain kernel is the faster one.
+    // Small batches: the agents of a chunk dealt out over two to A waves (mg_rollout_split_kernel) — a step is then the latency of
+    // one wave, and a wave does a third (half, ...) of the views.  A chunk's waves sit in one workgroup (they meet at a barrier
+    // between reading its state and writing it back).  Table path: one workgroup per CU holding the CU's share of chunks, while
+    // that share times the waves per chunk fits the workgroup's 16 waves.  Generic path (four waves' staging per workgroup): a
+    // chunk per workgroup, while all of them are resident at two waves per SIMD.  Beyond that the action phase done several
+    // times over costs throughput, and the plain kernel is the faster one.
     const void* split_fn = h->roll_split_fn[rt ? 1 : 0][std_cfg ? 1 : 0];
-    const int A = c.n_agents, cap = std::max(1, (rt ? 16 : 4) / A);
-    int cpb = rt ? (int)std::min<int64_t>(per_cu_chunks, cap) : 1;       // chunks per workgroup
-    while (cpb > 1 && fixed + (size_t)cpb * A * per_wave > (size_t)kLdsLimit) --cpb;
-    bool split = split_fn && A > 1 && (rt ? per_cu_chunks <= cpb : h->n_chunks * A <= (int64_t)h->n_cu * 8);
-    if (const char* e = debug_env("MG_DEBUG_ROLL_SPLIT")) split = split_fn && A > 1 && atoi(e) != 0;   // tests / A-B timing
+    const int A = c.n_agents, cap = rt ? 16 : 4;                          // waves per workgroup
+    // waves per chunk: A, while the CU's share of chunks times A fits one workgroup (three agents: up to 5 chunks per CU = 81920
+    // envs).  The kernel takes any number from two up (wave `me` does agents me, me + parts, ...); two waves per chunk for 6 to 8
+    // chunks per CU were measured and lose to the plain kernel (98304 envs 6.26 against 5.90 us per step, 131072 8.39 against
+    // 6.87): from about six chunks per CU the chip is full and the action phase done twice is paid in throughput.
+    int parts = 0, cpb = 1;                                               // chunks per workgroup
+    if (rt) {
+      if (per_cu_chunks * A <= cap && fixed + (size_t)per_cu_chunks * A * per_wave <= (size_t)kLdsLimit) { parts = A; cpb = (int)per_cu_chunks; }
+    } else if (A <= cap + 1 && h->n_chunks * A <= (int64_t)h->n_cu * 8) parts = A;
+    bool split = split_fn && A > 1 && parts > 0;
+    if (const char* e = debug_env("MG_DEBUG_ROLL_SPLIT")) {   // tests / A-B timing: 0 off, 1 on, 2.. on with that many waves per chunk
+      split = split_fn && A > 1 && atoi(e) != 0;
+      if (split && (atoi(e) > 1 || !parts)) {
+        parts = std::min(A, std::max(2, atoi(e) > 1 ? atoi(e) : A));
+        cpb = (int)std::max<int64_t>(1, std::min<int64_t>(per_cu_chunks, cap / parts));
+        while (cpb > 1 && fixed + (size_t)cpb * parts * per_wave > (size_t)kLdsLimit) --cpb;
+      }
+    }
     if (split) {
-      if (const char* e = debug_env("MG_DEBUG_SPLIT_CPB")) cpb = std::max(1, std::min(atoi(e), cap));   // tuning experiments only
-      const int snw = cpb * A;
+      if (const char* e = debug_env("MG_DEBUG_SPLIT_CPB")) cpb = std::max(1, std::min(atoi(e), std::max(1, cap / parts)));   // tuning experiments only
+      p.roll_split = (uint32_t)parts;
+      const int snw = cpb * parts;
       const size_t slds = fixed + snw * per_wave;
       const int per_cu = std::max(1, std::min((int)((size_t)kLdsLimit / slds), 32 / snw));
       unsigned sgrid = (unsigned)std::min<int64_t>((h->n_chunks + cpb - 1) / cpb, (int64_t)h->n_cu * per_cu);

@@ -112,9 +112,9 @@ def test_agent_split_rollout_kernel_equals_the_plain_one(cluttered_cells, monkey
   g = torch.Generator(device='cpu').manual_seed(A * 10 + V)
   ring = torch.randint(0, 7, (K, n, A), dtype=torch.uint8, generator=g)
   out = []
-  for split in ('1', '0'):
+  for split in ('1', '2', '0'):                    # A waves per chunk, two (agents {0, 2, 4} and {1, 3}), the plain kernel
     monkeypatch.setenv('MG_DEBUG_ROLL_SPLIT', split)
-    if split == '1':
+    if split != '0':
       monkeypatch.setenv('MG_DEBUG_GRID', '5')   # workgroups take several turns: a chunk's waves read its state before any writes it back
     else:
       monkeypatch.delenv('MG_DEBUG_GRID', raising=False)
@@ -127,11 +127,12 @@ def test_agent_split_rollout_kernel_equals_the_plain_one(cluttered_cells, monkey
                     state=env._env_state[:n].clone(), obs=env._obs_image[:, :n].clone(), rew=env._reward[:, :n].clone(), dd=env._dir_done[:n].clone()))
     assert env.check_errors() == 0 and env.step_index == 2 * K
     env.close()
-  for k in out[0]:
-    a, b = out[0][k], out[1][k]
-    if a.dtype in (torch.float64, torch.float32):
-      a, b = a.view(torch.int64 if a.dtype == torch.float64 else torch.int32), b.view(torch.int64 if b.dtype == torch.float64 else torch.int32)
-    assert torch.equal(a, b), k
+  for other in (1, 2):
+    for k in out[0]:
+      a, b = out[0][k], out[other][k]
+      if a.dtype in (torch.float64, torch.float32):
+        a, b = a.view(torch.int64 if a.dtype == torch.float64 else torch.int32), b.view(torch.int64 if b.dtype == torch.float64 else torch.int32)
+      assert torch.equal(a, b), (k, other)
   if kw.get('reward_dtype') != 'f32':
     orc = c_oracle.OracleBatch(cluttered_cells, n, A=A, V=V, max_steps=30, shaping={'v8': 1, None: 0, 'v7': 2}[kw.get('shaping', 'v8')],
                                auto_reset=int(kw.get('auto_reset', True)), seed=A + V)
