@@ -1565,8 +1565,15 @@ void launch_geometry(const mg_handle* h, bool table, int* nw_out, unsigned* grid
   const int rowb = h->cfg.view_size * h->cfg.view_size * 3;
   const size_t fixed = lds_fixed_bytes(h, table), per_wave = (size_t)kWave * rowb;
   int nw = table ? 16 : 4;
-  if (const char* e = debug_env("MG_DEBUG_NW")) nw = atoi(e);   // tuning experiments only
-  while (nw > 1 && (fixed + nw * per_wave > (size_t)kLdsLimit || h->n_chunks < (int64_t)h->n_cu * nw)) nw >>= 1;
+  if (const char* e = debug_env("MG_DEBUG_NW")) {   // tuning experiments only (and the geometry up to round 3's end: powers of two)
+    nw = atoi(e);
+    while (nw > 1 && (fixed + nw * per_wave > (size_t)kLdsLimit || h->n_chunks < (int64_t)h->n_cu * nw)) nw >>= 1;
+  } else {
+    while (nw > 1 && fixed + nw * per_wave > (size_t)kLdsLimit) nw >>= 1;
+    // a small batch: a workgroup per CU with the CU's share of chunks as its waves (any number — 3, 5, 7 — not only powers
+    // of two), so that no CU holds two workgroups' fills and no wave a second chunk while others have none
+    nw = (int)std::min<int64_t>(nw, std::max<int64_t>(1, (h->n_chunks + h->n_cu - 1) / h->n_cu));
+  }
   const size_t lds = fixed + nw * per_wave;
   int per_cu = (int)((size_t)kLdsLimit / lds);
   per_cu = std::max(1, std::min(per_cu, 32 / nw));
@@ -1612,7 +1619,7 @@ bool dyn_geometry(const mg_handle* h, int* nw_out, unsigned* grid_out, size_t* l
     if (resident > best) { best = resident; nw = cand; }
   }
   if (nw == 0) return false;
-  if (parts == 1) { while (nw > 1 && h->n_chunks < (int64_t)h->n_cu * nw) nw >>= 1; }
+  if (parts == 1) nw = (int)std::min<int64_t>(nw, std::max<int64_t>(1, (h->n_chunks + h->n_cu - 1) / h->n_cu));   // the CU's share of chunks, any number (launch_geometry)
   else { while (nw > parts && h->n_chunks * parts < (int64_t)h->n_cu * nw) nw -= parts; }
   const size_t lds = fixed + nw * per_wave;
   int per_cu = (int)((size_t)kLdsLimit / lds);
