@@ -1725,6 +1725,22 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     // the free-running step — no injected draws, no mask, no env_reward output — runs its own instantiation (mg_dyn.h FREE)
     const void* free_fn = h->dyn_free_fn[dyn_dec_index(h)];
     if (free_fn && op == OP_STEP && !order && !respawn && !reset_spawn && !objdrop && !reset_gen && !scatter && !mask && !h->buf.env_reward) {
+      // a small batch (at most four waves per CU with A waves per chunk; every chunk's waves resident at once): the fused rollout
+      // kernel with the agents over waves, as a rollout of ONE step into the step's own destinations — the same free-running
+      // step, a third of the views per wave: DoorKey-8x8 x 3 at 4096 envs 16.9 -> 13.7 us, 16384 envs 17.9 -> 14.8; from six
+      // waves per CU on (32768 envs) it no longer pays.  (MG_DEBUG_STEP_SPLIT=0 keeps the step kernel: tests, A/B timing)
+      bool one_trip = false;
+      const char* e = debug_env("MG_DEBUG_STEP_SPLIT");
+      if (c.n_agents > 1 && h->dyn_roll_fn[dyn_dec_index(h)] && (actions != nullptr) != (random_actions != 0) && !(e && atoi(e) == 0) &&
+          h->n_chunks * c.n_agents <= (int64_t)h->n_cu * 4 && dyn_geometry(h, &nw, &grid, &lds, 1, c.n_agents, &one_trip) && one_trip) {
+        p.n_roll = 1; p.roll_split = 1u;
+        p.traj_obs = h->full_obs ? p.obs_full : p.obs_image; p.traj_reward = p.reward; p.traj_dd = p.dir_done;
+        p.traj_actions = p.actions_out;
+        p.obs_full = nullptr; p.obs_image = nullptr; p.reward = nullptr; p.dir_done = nullptr;   // (a rollout's second set of destinations: none)
+        void* kargs[] = {&p};
+        HIP_TRY(hipLaunchKernel(h->dyn_roll_fn[dyn_dec_index(h)], dim3(grid), dim3(nw * kWave), kargs, lds, h->stream));
+        return dest ? launch_ep_stats(h, op, mask, 1, dest) : launch_ep_stats(h, op, mask, 0, nullptr);
+      }
       dyn_geometry(h, &nw, &grid, &lds, 2);
       void* kargs[] = {&p};
       HIP_TRY(hipLaunchKernel(free_fn, dim3(grid), dim3(nw * kWave), kargs, lds, h->stream));
@@ -1808,6 +1824,30 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     return launch_ep_stats(h, op, mask, n_roll, roll);
   }
   const bool table = launch_uses_table(h);
+  // A plain step of a small batch (generic path, all chunks' A waves resident at two per SIMD): the agents-over-waves kernel
+  // as a rollout of ONE step into the handle's own buffers — the same free-running step (mg_rollout_split_kernel is tested
+  // against K step launches bit for bit), a third of the views per wave: 4096 envs 9.80 -> 7.11 us per step launch.
+  // MG_DEBUG_STEP_SPLIT=0 keeps the step kernel (tests, A/B timing).
+  if (op == OP_STEP && !table && c.n_agents > 1 && (actions != nullptr) != (random_actions != 0) && !order && !respawn && !reset_spawn &&
+      !mask && !h->buf.env_reward && h->n_chunks * c.n_agents <= (int64_t)h->n_cu * 8) {
+    const bool std_cfg = p.shaping == MG_SHAPING_V8 && p.auto_reset && !p.competitive && h->fixed_mode == MG_FIXED_OFF &&
+                         !p.reward_f32 && !c.see_through_walls && !debug_env("MG_DEBUG_ROLL_GENERAL");
+    const void* split_fn = h->roll_split_fn[0][std_cfg ? 1 : 0];
+    const char* e = debug_env("MG_DEBUG_STEP_SPLIT");
+    if (split_fn && !(e && atoi(e) == 0)) {
+      const int A = c.n_agents;
+      p.n_roll = 1; p.roll_split = (uint32_t)A;
+      p.traj_obs = p.obs_image; p.traj_reward = p.reward; p.traj_dd = p.dir_done; p.traj_actions = p.actions_out;
+      p.obs_image = nullptr; p.reward = nullptr; p.dir_done = nullptr;      // (a rollout's second set of destinations: none)
+      const size_t slds = lds_fixed_bytes(h, false) + (size_t)A * kWave * c.view_size * c.view_size * 3;
+      const int per_cu = std::max(1, std::min((int)((size_t)kLdsLimit / slds), 32 / A));
+      unsigned sgrid = (unsigned)std::min<int64_t>(h->n_chunks, (int64_t)h->n_cu * per_cu);
+      if (const char* ge = debug_env("MG_DEBUG_GRID")) sgrid = (unsigned)std::max(1, std::min<int>(sgrid, atoi(ge)));   // tests only
+      void* kargs[] = {&p};
+      HIP_TRY(hipLaunchKernel(split_fn, dim3(sgrid), dim3(A * kWave), kargs, slds, h->stream));
+      return launch_ep_stats(h, op, mask, 0, nullptr);
+    }
+  }
   launch_geometry(h, table, &nw, &grid, &lds);
   const int fast = (op == OP_STEP && !order && !respawn && !reset_spawn && !random_actions && !h->buf.env_reward && !p.reward_f32) ? 1 : 0;
   hipLaunchKernelGGL(table ? h->var->table[fast] : h->var->generic[fast], dim3(grid), dim3(nw * kWave), lds, h->stream, p);

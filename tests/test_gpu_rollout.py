@@ -460,3 +460,81 @@ def test_standard_config_instantiation_equals_the_general_one(cluttered_cells, m
   for k in range(K):
     orc.step(None)
     assert np.array_equal(img[k], orc.obs_image[:, :n]) and np.array_equal(rew[k].view(np.int64), orc.reward[:, :n].view(np.int64)), k
+
+
+@pytest.mark.parametrize('A,V,kw', [(3, 5, {}), (2, 5, dict(shaping=None)), (5, 5, dict(auto_reset=False)), (3, 7, dict(competitive=True)),
+                                    (3, 5, dict(reward_dtype='f32')), (4, 5, dict(shaping='v7', see_through_walls=True))])
+def test_small_batch_step_runs_the_agent_split_kernel_and_equals_the_step_kernel(cluttered_cells, monkeypatch, A, V, kw):
+  """A plain mg_step / mg_step_random of a small batch is launched as a one-step rollout of mg_rollout_split_kernel into the handle's
+  own buffers (MG_DEBUG_STEP_SPLIT=0 keeps the step kernel): same obs, rewards, dir-done, drawn actions and env_state as the step
+  kernel at every step, across auto-resets, ragged batch, few workgroups (several turns each)."""
+  _need_gpu()
+  from multigrid_amd.batched import BatchedMultiGrid
+  n, T = 1500, 70
+  g = torch.Generator(device='cpu').manual_seed(A + 10 * V)
+  acts = torch.randint(0, 7, (T, A, n), dtype=torch.uint8, generator=g)
+  out = []
+  for split in ('1', '0'):
+    monkeypatch.setenv('MG_DEBUG_STEP_SPLIT', split)
+    if split == '1':
+      monkeypatch.setenv('MG_DEBUG_GRID', '5')
+    else:
+      monkeypatch.delenv('MG_DEBUG_GRID', raising=False)
+    env = BatchedMultiGrid(cluttered_cells, n_envs=n, n_agents=A, view_size=V, max_steps=25, seed=3 * A + V, **kw)
+    env.reset()
+    rec = []
+    drawn = torch.zeros((env.stride, env.slots), dtype=torch.uint8, device=env.device)
+    for t in range(T):
+      if t % 2:
+        env.step(acts[t].to(env.device))
+      else:
+        env.step_random(actions_out=drawn)
+        rec.append(drawn.clone())
+      rec += [env._obs_image[:, :n].clone(), env._reward[:, :n].clone(), env._dir_done[:n].clone(), env._env_state[:n].clone()]
+    assert env.check_errors() == 0
+    out.append(rec)
+    env.close()
+  assert len(out[0]) == len(out[1])
+  for i, (a, b) in enumerate(zip(out[0], out[1])):
+    if a.dtype in (torch.float64, torch.float32):
+      a, b = a.view(torch.int64 if a.dtype == torch.float64 else torch.int32), b.view(torch.int64 if b.dtype == torch.float64 else torch.int32)
+    assert torch.equal(a, b), i
+
+
+@pytest.mark.parametrize('env_id', ['MultiGrid-DoorKey-8x8-v0', 'MultiGrid-DoorKey-16x16-v0', 'MultiGrid-Cluttered-v0', 'MultiGrid-Meetup-Random-8x8-v0',
+                                    'MultiGrid-FourRooms-15x15-v0', 'MultiGrid-DoorKey-6x6-v0'])
+def test_small_batch_step_on_mutable_grids_runs_the_agent_split_kernel_and_equals_the_step_kernel(monkeypatch, env_id):
+  """The same on the mutable-grid kinds: a plain step of a small batch is a one-step launch of mg_dyn_rollout_kernel with the agents over
+  waves; against the FREE step kernel (MG_DEBUG_STEP_SPLIT=0) at every step — obs, rewards, dir-done, drawn actions, agent state, carried
+  objects and the grids themselves."""
+  _need_gpu()
+  from multigrid_amd import registry
+  n, T = 900, 60
+  A = registry.spec(env_id)['n_agents']
+  g = torch.Generator(device='cpu').manual_seed(len(env_id))
+  acts = torch.randint(0, 7, (T, A, n), dtype=torch.uint8, generator=g)
+  out = []
+  for split in ('1', '0'):
+    monkeypatch.setenv('MG_DEBUG_STEP_SPLIT', split)
+    env = registry.make_batched(env_id, n, seed=41, max_steps=20)
+    env.reset()
+    rec = []
+    drawn = torch.zeros((env.stride, env.slots), dtype=torch.uint8, device=env.device)
+    for t in range(T):
+      if t % 2:
+        env.step(acts[t].to(env.device))
+      else:
+        env.step_random(actions_out=drawn)
+        rec.append(drawn.clone())
+      img = env.obs_full if env.obs_full is not None else env.obs_image
+      rec += [img.clone(), env.reward.clone(), env.done.clone(), env.obs_dir.clone(), env.agent_state.clone(), env.carry.clone()]
+      if t % 10 == 9:
+        rec.append(env.grid_kinds().clone())
+    assert env.check_errors() == 0
+    out.append(rec)
+    env.close()
+  assert len(out[0]) == len(out[1])
+  for i, (a, b) in enumerate(zip(out[0], out[1])):
+    if a.dtype in (torch.float64, torch.float32):
+      a, b = a.view(torch.int64 if a.dtype == torch.float64 else torch.int32), b.view(torch.int64 if b.dtype == torch.float64 else torch.int32)
+    assert torch.equal(a, b), (env_id, i)
