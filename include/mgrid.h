@@ -404,8 +404,10 @@ int mg_check_errors(mg_handle* h, uint32_t* out);
  * scanning x-major, (13,13) if none). */
 int mg_get_goal(mg_handle* h, int32_t* gx, int32_t* gy);
 
-/* Kernel path actually in use (MG_PATH_GENERIC / MG_PATH_TABLE) and its launch geometry; any
- * out pointer may be NULL.  No reference counterpart (diagnostics for DESIGN.md / bench.py). */
+/* Kernel path actually in use (MG_PATH_GENERIC / MG_PATH_TABLE) and the launch geometry of a plain
+ * mg_step on this handle (a small batch: the kernel that deals a chunk's agents out over waves, as
+ * many waves per workgroup as agents); any out pointer may be NULL.  No reference counterpart
+ * (diagnostics for DESIGN.md / bench.py). */
 int mg_get_launch_info(mg_handle* h, int32_t* path, int32_t* block_threads, int32_t* grid_blocks, int32_t* lds_bytes);
 
 /* Test hook (no reference counterpart): MiniGridEnv._reward() = 1 - 0.9*(s/max_steps) as the

@@ -1653,6 +1653,37 @@ int launch_ep_stats(mg_handle* h, int op, const uint8_t* mask, int n_roll, const
   return MG_OK;
 }
 
+// Whether a free-running step of this handle — mg_step / mg_step_random with no injected draws and no mask, on a handle without the
+// env_reward output — is launched as a one-step rollout of the agents-over-waves kernels (mg_rollout_split_kernel; on mutable
+// grids mg_dyn_rollout_kernel with roll_split) into the handle's own buffers, and with what geometry.  Small batches only: all
+// chunks' A waves resident at two per SIMD on a shared map (generic path), at most four waves per CU on mutable grids (from six
+// on it no longer pays there).  MG_DEBUG_STEP_SPLIT=0 keeps the step kernels (tests, A/B timing).
+bool step_split_plan(const mg_handle* h, const void** fn, int* nw, unsigned* grid, size_t* lds) {
+  const mg_config& c = h->cfg;
+  const int A = c.n_agents;
+  const char* e = debug_env("MG_DEBUG_STEP_SPLIT");
+  if (A < 2 || h->buf.env_reward || (e && atoi(e) == 0)) return false;
+  if (h->dynamic) {
+    const void* f = h->dyn_roll_fn[dyn_dec_index(h)];
+    bool one_trip = false;
+    if (!f || !h->dyn_free_fn[dyn_dec_index(h)] || h->n_chunks * A > (int64_t)h->n_cu * 4) return false;
+    if (!dyn_geometry(h, nw, grid, lds, 1, A, &one_trip) || !one_trip) return false;
+    *fn = f;
+    return true;
+  }
+  if (launch_uses_table(h) || h->n_chunks * A > (int64_t)h->n_cu * 8) return false;
+  const bool std_cfg = c.shaping_kind == MG_SHAPING_V8 && c.auto_reset && !c.competitive && h->fixed_mode == MG_FIXED_OFF &&
+                       c.reward_dtype != MG_REWARD_F32 && !c.see_through_walls && !debug_env("MG_DEBUG_ROLL_GENERAL");
+  const void* f = h->roll_split_fn[0][std_cfg ? 1 : 0];
+  if (!f) return false;
+  const size_t slds = lds_fixed_bytes(h, false) + (size_t)A * kWave * c.view_size * c.view_size * 3;
+  const int per_cu = std::max(1, std::min((int)((size_t)kLdsLimit / slds), 32 / A));
+  unsigned sgrid = (unsigned)std::min<int64_t>(h->n_chunks, (int64_t)h->n_cu * per_cu);
+  if (const char* ge = debug_env("MG_DEBUG_GRID")) sgrid = (unsigned)std::max(1, std::min<int>(sgrid, atoi(ge)));   // tests only
+  *fn = f; *nw = A; *grid = sgrid; *lds = slds;
+  return true;
+}
+
 // dest (mutable-grid step launches only): this launch writes its obs / rewards / dir-done there instead of into the handle's
 // own buffers — a slot of a caller's trajectory (mg_rollout on these kinds).  The handle itself is not touched, so a
 // concurrent mg_get_buffers never sees a caller's pointers.
@@ -1725,20 +1756,17 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     // the free-running step — no injected draws, no mask, no env_reward output — runs its own instantiation (mg_dyn.h FREE)
     const void* free_fn = h->dyn_free_fn[dyn_dec_index(h)];
     if (free_fn && op == OP_STEP && !order && !respawn && !reset_spawn && !objdrop && !reset_gen && !scatter && !mask && !h->buf.env_reward) {
-      // a small batch (at most four waves per CU with A waves per chunk; every chunk's waves resident at once): the fused rollout
-      // kernel with the agents over waves, as a rollout of ONE step into the step's own destinations — the same free-running
-      // step, a third of the views per wave: DoorKey-8x8 x 3 at 4096 envs 16.9 -> 13.7 us, 16384 envs 17.9 -> 14.8; from six
-      // waves per CU on (32768 envs) it no longer pays.  (MG_DEBUG_STEP_SPLIT=0 keeps the step kernel: tests, A/B timing)
-      bool one_trip = false;
-      const char* e = debug_env("MG_DEBUG_STEP_SPLIT");
-      if (c.n_agents > 1 && h->dyn_roll_fn[dyn_dec_index(h)] && (actions != nullptr) != (random_actions != 0) && !(e && atoi(e) == 0) &&
-          h->n_chunks * c.n_agents <= (int64_t)h->n_cu * 4 && dyn_geometry(h, &nw, &grid, &lds, 1, c.n_agents, &one_trip) && one_trip) {
+      // a small batch: the fused rollout kernel with the agents over waves, as a rollout of ONE step into the step's own
+      // destinations — the same free-running step, a third of the views per wave (step_split_plan): DoorKey-8x8 x 3 at 4096
+      // envs 16.9 -> 13.7 us, 16384 envs 17.9 -> 14.8
+      const void* split_fn = nullptr;
+      if ((actions != nullptr) != (random_actions != 0) && step_split_plan(h, &split_fn, &nw, &grid, &lds)) {
         p.n_roll = 1; p.roll_split = 1u;
         p.traj_obs = h->full_obs ? p.obs_full : p.obs_image; p.traj_reward = p.reward; p.traj_dd = p.dir_done;
         p.traj_actions = p.actions_out;
         p.obs_full = nullptr; p.obs_image = nullptr; p.reward = nullptr; p.dir_done = nullptr;   // (a rollout's second set of destinations: none)
         void* kargs[] = {&p};
-        HIP_TRY(hipLaunchKernel(h->dyn_roll_fn[dyn_dec_index(h)], dim3(grid), dim3(nw * kWave), kargs, lds, h->stream));
+        HIP_TRY(hipLaunchKernel(split_fn, dim3(grid), dim3(nw * kWave), kargs, lds, h->stream));
         return dest ? launch_ep_stats(h, op, mask, 1, dest) : launch_ep_stats(h, op, mask, 0, nullptr);
       }
       dyn_geometry(h, &nw, &grid, &lds, 2);
@@ -1824,29 +1852,18 @@ int launch(mg_handle* h, int op, const void* actions, const uint8_t* order, cons
     return launch_ep_stats(h, op, mask, n_roll, roll);
   }
   const bool table = launch_uses_table(h);
-  // A plain step of a small batch (generic path, all chunks' A waves resident at two per SIMD): the agents-over-waves kernel
-  // as a rollout of ONE step into the handle's own buffers — the same free-running step (mg_rollout_split_kernel is tested
-  // against K step launches bit for bit), a third of the views per wave: 4096 envs 9.80 -> 7.11 us per step launch.
-  // MG_DEBUG_STEP_SPLIT=0 keeps the step kernel (tests, A/B timing).
-  if (op == OP_STEP && !table && c.n_agents > 1 && (actions != nullptr) != (random_actions != 0) && !order && !respawn && !reset_spawn &&
-      !mask && !h->buf.env_reward && h->n_chunks * c.n_agents <= (int64_t)h->n_cu * 8) {
-    const bool std_cfg = p.shaping == MG_SHAPING_V8 && p.auto_reset && !p.competitive && h->fixed_mode == MG_FIXED_OFF &&
-                         !p.reward_f32 && !c.see_through_walls && !debug_env("MG_DEBUG_ROLL_GENERAL");
-    const void* split_fn = h->roll_split_fn[0][std_cfg ? 1 : 0];
-    const char* e = debug_env("MG_DEBUG_STEP_SPLIT");
-    if (split_fn && !(e && atoi(e) == 0)) {
-      const int A = c.n_agents;
-      p.n_roll = 1; p.roll_split = (uint32_t)A;
-      p.traj_obs = p.obs_image; p.traj_reward = p.reward; p.traj_dd = p.dir_done; p.traj_actions = p.actions_out;
-      p.obs_image = nullptr; p.reward = nullptr; p.dir_done = nullptr;      // (a rollout's second set of destinations: none)
-      const size_t slds = lds_fixed_bytes(h, false) + (size_t)A * kWave * c.view_size * c.view_size * 3;
-      const int per_cu = std::max(1, std::min((int)((size_t)kLdsLimit / slds), 32 / A));
-      unsigned sgrid = (unsigned)std::min<int64_t>(h->n_chunks, (int64_t)h->n_cu * per_cu);
-      if (const char* ge = debug_env("MG_DEBUG_GRID")) sgrid = (unsigned)std::max(1, std::min<int>(sgrid, atoi(ge)));   // tests only
-      void* kargs[] = {&p};
-      HIP_TRY(hipLaunchKernel(split_fn, dim3(sgrid), dim3(A * kWave), kargs, slds, h->stream));
-      return launch_ep_stats(h, op, mask, 0, nullptr);
-    }
+  // A plain step of a small batch: the agents-over-waves kernel as a rollout of ONE step into the handle's own buffers — the
+  // same free-running step (mg_rollout_split_kernel is tested against K step launches bit for bit), a third of the views per
+  // wave (step_split_plan): 4096 envs 9.80 -> 7.11 us per step launch.
+  const void* split_fn = nullptr;
+  if (op == OP_STEP && (actions != nullptr) != (random_actions != 0) && !order && !respawn && !reset_spawn && !mask &&
+      step_split_plan(h, &split_fn, &nw, &grid, &lds)) {
+    p.n_roll = 1; p.roll_split = (uint32_t)c.n_agents;
+    p.traj_obs = p.obs_image; p.traj_reward = p.reward; p.traj_dd = p.dir_done; p.traj_actions = p.actions_out;
+    p.obs_image = nullptr; p.reward = nullptr; p.dir_done = nullptr;      // (a rollout's second set of destinations: none)
+    void* kargs[] = {&p};
+    HIP_TRY(hipLaunchKernel(split_fn, dim3(grid), dim3(nw * kWave), kargs, lds, h->stream));
+    return launch_ep_stats(h, op, mask, 0, nullptr);
   }
   launch_geometry(h, table, &nw, &grid, &lds);
   const int fast = (op == OP_STEP && !order && !respawn && !reset_spawn && !random_actions && !h->buf.env_reward && !p.reward_f32) ? 1 : 0;
@@ -2586,8 +2603,11 @@ int mg_get_goal(mg_handle* h, int32_t* gx, int32_t* gy) {
 int mg_get_launch_info(mg_handle* h, int32_t* path, int32_t* block_threads, int32_t* grid_blocks, int32_t* lds_bytes) {
   if (!h) return fail(MG_EINVAL, "null handle");
   int nw; unsigned grid; size_t lds;
-  // the geometry of a plain mg_step launch: on a mutable-grid handle without the env_reward output that is the FREE instantiation
-  if (h->dynamic) dyn_geometry(h, &nw, &grid, &lds, (h->dyn_free_fn[dyn_dec_index(h)] && !h->buf.env_reward) ? 2 : 0);
+  const void* split_fn = nullptr;
+  // the geometry of a plain mg_step launch: a small batch runs the agents-over-waves kernels (step_split_plan); otherwise, on a
+  // mutable-grid handle without the env_reward output, the FREE instantiation
+  if (step_split_plan(h, &split_fn, &nw, &grid, &lds)) {}
+  else if (h->dynamic) dyn_geometry(h, &nw, &grid, &lds, (h->dyn_free_fn[dyn_dec_index(h)] && !h->buf.env_reward) ? 2 : 0);
   else launch_geometry(h, launch_uses_table(h), &nw, &grid, &lds);
   if (path) *path = launch_uses_table(h) ? MG_PATH_TABLE : MG_PATH_GENERIC;
   if (block_threads) *block_threads = nw * kWave;
